@@ -1,0 +1,104 @@
+/* C-ABI of libmmu_hip.so — the MI355X (gfx950) kernels behind the forget/retain step.
+ *
+ * The reference (somvy/multimodal_unlearning) is pure Python and has no native ABI; each entry point below
+ * names the reference call (file:line under /root/reference, or the transformers op that call reaches)
+ * whose arithmetic it replaces.  Conventions:
+ *   - every pointer is a DEVICE pointer unless named host_*; bf16 tensors are `void*` to raw bfloat16 bits;
+ *   - row-major, leading dimensions in ELEMENTS; `stream` is a hipStream_t (0 = default stream);
+ *   - nothing allocates, synchronises or touches host memory: safe to capture into a hipGraph;
+ *   - return 0 on success, a hipError_t (>0) from the runtime, or -1 for an unsupported argument.
+ */
+#ifndef MMU_HIP_H
+#define MMU_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ABI version, bumped on any signature change. */
+int mmu_abi_version(void);
+
+/* ---- GEMM (nn.Linear fwd / dgrad / wgrad reached from mm/trainer.py:180-433 `model(**inputs)` and the
+ * backward of mm/forget.py:190 trainer.train(); SURVEY §8a K1,K3,K5,K8,K11,K12,K13) ----
+ * C[M,N] = epi(sum_k Aop[m,k] Bop[n,k]), fp32 accumulate, bf16 out.
+ * layout 0 (NT): A[M][K], B[N][K]   forward  y = x W^T
+ * layout 1 (NN): A[M][K], B[K][N]   dgrad    dx = dy W
+ * layout 2 (TN): A[K][M], B[K][N]   wgrad    dW = dy^T x
+ * epi: v = bf16(acc + bias[n]); act (0 none, 1 gelu-erf, 2 quick-gelu) -> bf16; + resid[m][n] -> bf16
+ *      (the rounding points of transformers' bf16 modules); accumulate=1: C = bf16(float(C) + acc). */
+int mmu_gemm_bf16(int layout, const void* A, const void* B, void* C, const void* bias, const void* resid,
+                  int M, int N, int K, int lda, int ldb, int ldc, int ldr, int act, int accumulate, void* stream);
+
+/* ---- Attention (replaces the flash-attn wheel: mm/forget.py:86,98,106 attn_implementation=
+ * "flash_attention_2"; SURVEY §8a K3 (CLIP, non-causal, head_dim 64) and K10 (Llama, causal, 128)) ----
+ * q/k/v: rows of `ld` elements, head h at column h*head_dim of each pointer, sequence b = rows [b*S,(b+1)*S).
+ * lse [B][H][S] fp32 (natural log of the scaled-score partition; may be NULL forward-only).
+ * kmask [B][S] int32 (1 = key may be attended; NULL = all). */
+int mmu_attn_fwd(const void* q, const void* k, const void* v, int ld, void* o, int ldo, float* lse,
+                 const int* kmask, int B, int S, int H, int head_dim, float scale, int causal, void* stream);
+/* head_dim 128 only; delta [B][H][S] fp32 is workspace. */
+int mmu_attn_bwd(const void* q, const void* k, const void* v, int ld, const void* o, int ldo, const float* lse,
+                 const int* kmask, const void* dout, int lddo, float* delta, void* dq, void* dk, void* dv,
+                 int ldg, int B, int S, int H, int head_dim, float scale, int causal, void* stream);
+
+/* ---- Norms (LlamaRMSNorm / CLIP LayerNorm; SURVEY §8a K2,K7) ---- */
+int mmu_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int M, int d, float eps, void* stream);
+int mmu_rmsnorm_bwd_nparts(int M); /* dw_part must hold nparts*d floats */
+int mmu_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres, void* dx,
+                    float* dw_part, void* dw, int accumulate_dw, int M, int d, void* stream);
+int mmu_layernorm_fwd(const void* x, const void* w, const void* b, void* y, int M, int d, float eps, void* stream);
+
+/* ---- CLIP embeddings (CLIPVisionEmbeddings: patch conv as im2col+GEMM, cls/pos add; K1,K2) ---- */
+int mmu_im2col_patch(const float* pix, void* out, int B, int C, int H, int P, int Kpad, void* stream);
+int mmu_clip_embed(const void* patch, const void* cls, const void* pos, void* out, int B, int T, int d, void* stream);
+
+/* ---- RoPE on the fused qkv buffer, rotate-half convention (apply_rotary_pos_emb; K9) ---- */
+int mmu_rope_table(void* cos_t, void* sin_t, int n_pos, int head_dim, float theta, void* stream);
+int mmu_rope(void* qkv, const int* pos_ids, const void* cos_t, const void* sin_t, int M, int ld, int n_q_heads,
+             int n_k_heads, int head_dim, int k_off, int inverse, void* stream);
+
+/* ---- SwiGLU / GELU / add (LlamaMLP, LlavaMultiModalProjector act; K5,K12) ---- */
+int mmu_swiglu_fwd(const void* gate_up, void* h, int M, int I, void* stream);
+int mmu_swiglu_bwd(const void* gate_up, const void* dh, void* dgate_up, int M, int I, void* stream);
+int mmu_gelu_fwd(const void* x, void* y, long long n, void* stream);
+int mmu_gelu_bwd(const void* x, const void* dy, void* dx, long long n, void* stream);
+int mmu_add_bf16(const void* a, const void* b, void* out, long long n, void* stream);
+int mmu_colsum_nparts(int M); /* part must hold nparts*d floats */
+int mmu_colsum_bf16(const void* x, float* part, void* dst, int accumulate, int M, int d, void* stream);
+
+/* ---- Token embedding + image-feature scatter (modeling_llava.py masked_scatter; K6) ---- */
+int mmu_image_slots(const long long* ids, int M, long long image_token, int* slot, int* count, void* stream);
+int mmu_embed_fwd(const long long* ids, const int* slot, const void* table, const void* img, void* out, int M,
+                  int d, int vocab, void* stream);
+int mmu_embed_bwd(const long long* ids, const int* slot, const void* dh, void* dimg, float* scratch, int* flag,
+                  void* grad_table, int M, int d, int vocab, void* stream);
+
+/* ---- Losses over [N,V] bf16 logits (mm/trainer_utils.py:16-21 logits2probs, :73-81 get_batch_loss;
+ * F.kl_div call sites mm/trainer.py:203-208,220-225,237-242,250-255,271-276,294-299,435-440; NPO :348-353;
+ * entropy :195-196; the model's own shifted CE = `outputs.loss`; SURVEY §8a R3-R7,K14) ----
+ * labels are the UNSHIFTED [B][S] int64 labels; shift=1 applies the causal-LM shift (target of row (b,s) is
+ * labels[b][s+1], last position ignored); ignore_index = -100. */
+int mmu_ce_fwd(const void* logits, int ldv, const long long* labels, float* lse, float* loss_row, int M, int V,
+               int S, int shift, void* stream);
+int mmu_ce_bwd(const void* logits, int ldv, const long long* labels, const float* lse, const float* seg_scale,
+               const float* seg_cnt, int seg_rows, int normalize, void* dlogits, int ldd, int M, int V, int S,
+               int shift, void* stream);
+int mmu_seg_reduce(const float* vals, const long long* labels, int seg_rows, int M, int V, int S, int shift,
+                   float* out_sum, float* out_cnt, void* stream);
+/* mode 0: KL(input=student,target=teacher) 1: KL(input=teacher,target=student) 2: NPO 3: entropy sum p log p.
+ * stats [M][4] = {lse_s, lse_t, row value, aux}. */
+int mmu_rowloss_fwd(int mode, const void* slog, const void* tlog, int ldv, float beta, float* stats, int M, int V,
+                    void* stream);
+int mmu_rowloss_bwd(int mode, const void* slog, const void* tlog, int ldv, float beta, const float* stats,
+                    const float* coef, void* dlogits, int ldd, int M, int V, void* stream);
+
+/* ---- Optimiser step after compute_loss (HF loop: clip_grad_norm_ -> AdamW -> zero_grad; mm/forget.py:139-168) ---- */
+int mmu_sumsq_bf16(const void* g, long long n, float* out_sumsq, void* stream);
+int mmu_adamw_bf16(void* p, void* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, int step, const float* sumsq, float max_norm, float grad_scale, int zero_grad,
+                   void* stream);
+int mmu_scale_bf16(void* x, long long n, float s, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,619 @@
+// Fused (flash-style) attention forward + backward for gfx950, bf16 in / fp32 accumulate / bf16 out.
+// Replaces the flash-attn wheel the reference enables with attn_implementation="flash_attention_2"
+// (mm/forget.py:86,98,106; config/model_config.yaml:61) for the Llama decoder (causal, head_dim 128)
+// and the CLIP tower (non-causal, head_dim 64).  SURVEY.md §8a rows K3, K10.
+//
+// MFMA: v_mfma_f32_32x32x16_bf16.  Operand maps (guide §3): A frag lane l = A[row l&31][k 8(l>>5)+j],
+// B frag lane l = B[k 8(l>>5)+j][col l&31], D: col = l&31, row = (reg&3)+8(reg>>2)+4(l>>5).
+//
+// Forward / dQ kernels ("query on the lane"): S^T = K Q^T puts one query per lane and 16 keys in the
+// registers of each half-wave, so the softmax statistics are lane-local and the S^T accumulator is, after
+// bf16 packing, directly the B operand of the next product (O^T = V^T P^T, dQ^T = K^T dS^T) whose A operand
+// is read transposed from the row-major LDS tile with ds_read_b64_tr_b16.
+// dK/dV kernel ("key on the lane"): S = Q K^T, dP = dO V^T with K, V fragments resident in registers;
+// P and dS feed dV^T += dO^T P and dK^T += Q^T dS the same way.
+//
+// LDS tiles are [rows][D] row-major, lane-linear as LDS-DMA writes them, XOR-swizzled on the per-lane
+// source address and on the reads.  D=128 (256-B rows): chunk ^= ((row&3)<<2)|((row>>2)&3), which is
+// conflict-free for both ds_read_b128 row reads and transposed reads (guide T10 image (b)).
+#include "common.h"
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+enum { KIND_ROW = 0, KIND_TR = 1 };
+
+template <int D, int KIND>
+__device__ __forceinline__ int swz(int r) {
+    if (D == 128) return ((r & 3) << 2) | ((r >> 2) & 3);
+    // D == 64: 128-B rows (two rows per 256-B bank row)
+    return KIND == KIND_ROW ? ((r >> 1) & 7) : (((r >> 1) & 1) << 2);
+}
+
+// Stage R rows x D bf16 of a row-major matrix (row stride ld elements) into a swizzled LDS tile.
+// Rows >= row_limit read the zero page.
+template <int D, int KIND, int R>
+__device__ __forceinline__ void stage_rows(char* tile, const bf16* __restrict__ g, int ld, int row0, int row_limit,
+                                           int wave, int lane) {
+    constexpr int ROWB = D * 2, RPI = 1024 / ROWB, CPR = ROWB / 16, NI = R / RPI, PW = NI / 4;
+    static_assert(PW >= 1, "tile too small for 4 waves");
+    const bf16* zero = reinterpret_cast<const bf16*>(mmu_zero16);
+#pragma unroll
+    for (int i = 0; i < PW; ++i) {
+        const int t = wave * PW + i;
+        const int r = t * RPI + lane / CPR;
+        const int c = (lane % CPR) ^ swz<D, KIND>(r);
+        const bf16* src = (row0 + r < row_limit) ? (g + (size_t)(row0 + r) * ld + c * 8) : zero;
+        glds16(src, tile + t * 1024);
+    }
+}
+
+// Row-read fragment: lane l gets tile[base + (l&31)][16*ks + 8*(l>>5) + 0..7]
+template <int D, int KIND>
+__device__ __forceinline__ bf16x8 row_frag(const MMU_LDS char* tile, int base, int ks, int lane) {
+    const int r = base + (lane & 31);
+    const int ch = 2 * ks + (lane >> 5);
+    return *(const MMU_LDS bf16x8*)(tile + r * (D * 2) + ((ch ^ swz<D, KIND>(r)) << 4));
+}
+
+// Transposed fragment: lane l gets tile[rbase + 16*s + 8*(j>>2) + 4*(l>>5) + (j&3)][c0 + (l&31)], j = 0..7
+// (the k order of an accumulator tile used as the other operand, guide §3).
+template <int D, int KIND>
+__device__ __forceinline__ bf16x8 tr_frag(const MMU_LDS char* tile, int rbase, int s, int c0, int lane) {
+    const int g = lane >> 4, gb = g & 1, h = g >> 1, i = lane & 15, q = i >> 2, p = i & 3;
+    const int r1 = rbase + 16 * s + 4 * h + q;
+    const int r2 = r1 + 8;
+    const int ch = (c0 >> 3) + 2 * gb + (p >> 1);
+    const int sub = (p & 1) << 3;
+    const MMU_LDS char* a1 = tile + r1 * (D * 2) + ((ch ^ swz<D, KIND>(r1)) << 4) + sub;
+    const MMU_LDS char* a2 = tile + r2 * (D * 2) + ((ch ^ swz<D, KIND>(r2)) << 4) + sub;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((MMU_LDS bf16x4*)a1);
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((MMU_LDS bf16x4*)a2);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+__device__ __forceinline__ bf16x8 pack8(const f32x16& v, int s) {
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = f2bf(v[8 * s + j]);
+    return r;
+}
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+struct AttnArgs {
+    const bf16* q;
+    const bf16* k;
+    const bf16* v;
+    int ld;  // row stride of q/k/v (elements)
+    bf16* o;
+    int ldo;
+    float* lse;        // [B][H][S] natural-log lse of the scaled scores (+inf for rows with no valid key)
+    const int* kmask;  // [B][S] 1 = attend, 0 = masked key; may be null
+    int B, S, H;
+    float scale;
+    // backward
+    const bf16* dout;
+    int lddo;
+    const float* delta;  // [B][H][S]
+    bf16* dq;
+    bf16* dk;
+    bf16* dv;
+    int ldg;  // row stride of dq/dk/dv
+};
+
+// ------------------------------------------------------------------------------------------------
+// Forward. grid (ceil(S/128), H, B), 256 threads; wave w owns query rows qb*128 + 32w .. +31.
+// LDS: 2 x (K tile 64xD | V tile 64xD) + 2 x 64 floats key bias.
+// ------------------------------------------------------------------------------------------------
+template <int D, bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TB = 64 * D * 2;  // bytes per 64-row tile
+    constexpr int NKS = D / 16, NDT = D / 32;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int hl = lane >> 5;
+    const int qb = blockIdx.x, hh = blockIdx.y, b = blockIdx.z;
+    const int S = a.S;
+    const size_t rowbase = (size_t)b * S;
+    const bf16* qp = a.q + rowbase * a.ld + hh * D;
+    const bf16* kp = a.k + rowbase * a.ld + hh * D;
+    const bf16* vp = a.v + rowbase * a.ld + hh * D;
+    float* kbias = reinterpret_cast<float*>(smem + 4 * TB);  // [2][64]
+
+    const int q0 = qb * 128 + wave * 32;
+    const int qrow = q0 + (lane & 31);
+    const bool qvalid = qrow < S;
+    bf16x8 qf[NKS];
+    {
+        const bf16* qsrc = qp + (size_t)(qvalid ? qrow : S - 1) * a.ld + 8 * hl;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qsrc + 16 * ks);
+    }
+    f32x16 o[NDT];
+#pragma unroll
+    for (int i = 0; i < NDT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+    float m = -INFINITY, lsum = 0.f;
+    const float c = a.scale * LOG2E;
+
+    const int kv_end = CAUSAL ? min(S, qb * 128 + 128) : S;
+    const int nblk = (kv_end + 63) / 64;
+
+    auto stage = [&](int kb, int buf) {
+        char* base = smem + buf * 2 * TB;
+        stage_rows<D, KIND_ROW, 64>(base, kp, a.ld, kb * 64, S, wave, lane);
+        stage_rows<D, KIND_TR, 64>(base + TB, vp, a.ld, kb * 64, S, wave, lane);
+        if (threadIdx.x < 64) {
+            const int key = kb * 64 + threadIdx.x;
+            const bool ok = key < S && (a.kmask == nullptr || a.kmask[rowbase + key] != 0);
+            kbias[buf * 64 + threadIdx.x] = ok ? 0.f : -INFINITY;
+        }
+    };
+
+    stage(0, 0);
+    for (int kb = 0; kb < nblk; ++kb) {
+        const int cur = kb & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kb + 1 < nblk) stage(kb + 1, cur ^ 1);
+        const bool active = !CAUSAL || (kb * 64 <= q0 + 31);
+        if (active) {
+            const MMU_LDS char* kt = (const MMU_LDS char*)smem + cur * 2 * TB;
+            const MMU_LDS char* vt = kt + TB;
+            const MMU_LDS float* kbs = (const MMU_LDS float*)(smem + 4 * TB) + cur * 64;
+            f32x16 s[2];
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[st][r] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) {
+                    const bf16x8 kf = row_frag<D, KIND_ROW>(kt, st * 32, ks, lane);
+                    s[st] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[st], 0, 0, 0);
+                }
+            }
+            // scale (log2 domain), key bias, causal mask
+            const bool diag = CAUSAL && (kb * 64 + 63 > q0);
+            float mx = -INFINITY;
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int kl = st * 32 + 8 * g + 4 * hl;  // local key of reg 4g
+                    const f32x4 kb4 = *(const MMU_LDS f32x4*)(kbs + kl);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float x = s[st][4 * g + j] * c + kb4[j];
+                        if (diag && (kb * 64 + kl + j > qrow)) x = -INFINITY;
+                        s[st][4 * g + j] = x;
+                        mx = fmaxf(mx, x);
+                    }
+                }
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m, mx);
+            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = fast_exp2(m - m_use);
+            float rs = 0.f;
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = fast_exp2(s[st][r] - m_use);
+                    s[st][r] = p;
+                    rs += p;
+                }
+            lsum = lsum * alpha + rs;
+            m = m_new;
+#pragma unroll
+            for (int i = 0; i < NDT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+            // O^T[d][q] += V^T[d][key] P^T[key][q]
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int sk = 0; sk < 2; ++sk) {
+                    const bf16x8 pf = pack8(s[st], sk);
+#pragma unroll
+                    for (int dt = 0; dt < NDT; ++dt) {
+                        const bf16x8 vf = tr_frag<D, KIND_TR>(vt, st * 32, sk, dt * 32, lane);
+                        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
+                    }
+                }
+        }
+    }
+    const float ltot = lsum + __shfl_xor(lsum, 32, 64);
+    const float inv = ltot > 0.f ? 1.f / ltot : 0.f;
+    if (qvalid) {
+        bf16* op = a.o + (rowbase + qrow) * a.ldo + hh * D;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 t;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) t[j] = f2bf(o[dt][4 * g + j] * inv);
+                *reinterpret_cast<bf16x4*>(op + dt * 32 + 8 * g + 4 * hl) = t;
+            }
+        if (hl == 0 && a.lse)
+            a.lse[((size_t)b * a.H + hh) * S + qrow] = ltot > 0.f ? (m + __log2f(ltot)) * LN2 : INFINITY;
+    }
+}
+
+// delta[b][h][s] = sum_d dO[b,s,h,d] * O[b,s,h,d]   (one wave per (row, head))
+template <int D>
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict__ o, int ldo,
+                                                         const bf16* __restrict__ dout, int lddo,
+                                                         float* __restrict__ delta, int B, int S, int H) {
+    const int lane = threadIdx.x & 63;
+    const size_t idx = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // over B*S*H
+    const size_t total = (size_t)B * S * H;
+    if (idx >= total) return;
+    const int h = (int)(idx % H);
+    const size_t row = idx / H;
+    constexpr int PER = D / 64;  // elements per lane (2 or 1)
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int d = lane * PER + j;
+        acc += bf2f(o[row * ldo + h * D + d]) * bf2f(dout[row * lddo + h * D + d]);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) {
+        const int b = (int)(row / S), s = (int)(row % S);
+        delta[((size_t)b * H + h) * S + s] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dQ. Same geometry as forward. dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q],
+// dS^T = P^T * (dP^T - delta[q]) * scale, P^T = exp2(S^T c - lse2[q]), dP^T = V dO^T.
+// LDS: 2 x (K tile (row + transposed reads) | V tile (row reads)) + key bias.
+// ------------------------------------------------------------------------------------------------
+template <int D, bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TB = 64 * D * 2;
+    constexpr int NKS = D / 16, NDT = D / 32;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int hl = lane >> 5;
+    const int qb = blockIdx.x, hh = blockIdx.y, b = blockIdx.z;
+    const int S = a.S;
+    const size_t rowbase = (size_t)b * S;
+    const bf16* qp = a.q + rowbase * a.ld + hh * D;
+    const bf16* kp = a.k + rowbase * a.ld + hh * D;
+    const bf16* vp = a.v + rowbase * a.ld + hh * D;
+    const bf16* dop = a.dout + rowbase * a.lddo + hh * D;
+    float* kbias = reinterpret_cast<float*>(smem + 4 * TB);
+
+    const int q0 = qb * 128 + wave * 32;
+    const int qrow = q0 + (lane & 31);
+    const bool qvalid = qrow < S;
+    bf16x8 qf[NKS], dof[NKS];
+    {
+        const size_t rr = (size_t)(qvalid ? qrow : S - 1);
+        const bf16* qsrc = qp + rr * a.ld + 8 * hl;
+        const bf16* dsrc = dop + rr * a.lddo + 8 * hl;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            qf[ks] = *reinterpret_cast<const bf16x8*>(qsrc + 16 * ks);
+            dof[ks] = *reinterpret_cast<const bf16x8*>(dsrc + 16 * ks);
+        }
+    }
+    const size_t sidx = ((size_t)b * a.H + hh) * S + (qvalid ? qrow : S - 1);
+    const float lse2 = qvalid ? a.lse[sidx] * LOG2E : INFINITY;
+    const float dlt = a.delta[sidx];
+    f32x16 acc[NDT];
+#pragma unroll
+    for (int i = 0; i < NDT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    const float c = a.scale * LOG2E;
+
+    const int kv_end = CAUSAL ? min(S, qb * 128 + 128) : S;
+    const int nblk = (kv_end + 63) / 64;
+
+    auto stage = [&](int kb, int buf) {
+        char* base = smem + buf * 2 * TB;
+        stage_rows<D, KIND_ROW, 64>(base, kp, a.ld, kb * 64, S, wave, lane);
+        stage_rows<D, KIND_ROW, 64>(base + TB, vp, a.ld, kb * 64, S, wave, lane);
+        if (threadIdx.x < 64) {
+            const int key = kb * 64 + threadIdx.x;
+            const bool ok = key < S && (a.kmask == nullptr || a.kmask[rowbase + key] != 0);
+            kbias[buf * 64 + threadIdx.x] = ok ? 0.f : -INFINITY;
+        }
+    };
+
+    stage(0, 0);
+    for (int kb = 0; kb < nblk; ++kb) {
+        const int cur = kb & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kb + 1 < nblk) stage(kb + 1, cur ^ 1);
+        const bool active = !CAUSAL || (kb * 64 <= q0 + 31);
+        if (active) {
+            const MMU_LDS char* kt = (const MMU_LDS char*)smem + cur * 2 * TB;
+            const MMU_LDS char* vt = kt + TB;
+            const MMU_LDS float* kbs = (const MMU_LDS float*)(smem + 4 * TB) + cur * 64;
+            const bool diag = CAUSAL && (kb * 64 + 63 > q0);
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                f32x16 s, dp;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) {
+                    const bf16x8 kf = row_frag<D, KIND_ROW>(kt, st * 32, ks, lane);
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+                }
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) {
+                    const bf16x8 vf = row_frag<D, KIND_ROW>(vt, st * 32, ks, lane);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], dp, 0, 0, 0);
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int kl = st * 32 + 8 * g + 4 * hl;
+                    const f32x4 kb4 = *(const MMU_LDS f32x4*)(kbs + kl);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float x = s[4 * g + j] * c + kb4[j] - lse2;
+                        if (diag && (kb * 64 + kl + j > qrow)) x = -INFINITY;
+                        const float p = fast_exp2(x);
+                        s[4 * g + j] = p * (dp[4 * g + j] - dlt) * a.scale;
+                    }
+                }
+#pragma unroll
+                for (int sk = 0; sk < 2; ++sk) {
+                    const bf16x8 dsf = pack8(s, sk);
+#pragma unroll
+                    for (int dt = 0; dt < NDT; ++dt) {
+                        const bf16x8 ktf = tr_frag<D, KIND_ROW>(kt, st * 32, sk, dt * 32, lane);
+                        acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf, dsf, acc[dt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    if (qvalid) {
+        bf16* op = a.dq + (rowbase + qrow) * a.ldg + hh * D;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 t;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) t[j] = f2bf(acc[dt][4 * g + j]);
+                *reinterpret_cast<bf16x4*>(op + dt * 32 + 8 * g + 4 * hl) = t;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dK / dV. grid (ceil(S/128), H, B); wave w owns keys kvb*128 + 32w .. +31 ("key on the lane") and
+// keeps K, V fragments plus dK^T, dV^T accumulators in registers while the workgroup sweeps 32-row
+// query tiles (Q and dO tiles in LDS, read by rows for S / dP and transposed for dK^T / dV^T).
+// LDS: 2 x (Q tile 32xD | dO tile 32xD) + 2 x (32 lse2 | 32 delta).
+// ------------------------------------------------------------------------------------------------
+template <int D, bool CAUSAL>
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TB = 32 * D * 2;
+    constexpr int NKS = D / 16, NDT = D / 32;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int hl = lane >> 5;
+    const int kvb = blockIdx.x, hh = blockIdx.y, b = blockIdx.z;
+    const int S = a.S;
+    const size_t rowbase = (size_t)b * S;
+    const bf16* qp = a.q + rowbase * a.ld + hh * D;
+    const bf16* kp = a.k + rowbase * a.ld + hh * D;
+    const bf16* vp = a.v + rowbase * a.ld + hh * D;
+    const bf16* dop = a.dout + rowbase * a.lddo + hh * D;
+    const float* lsep = a.lse + ((size_t)b * a.H + hh) * S;
+    const float* dltp = a.delta + ((size_t)b * a.H + hh) * S;
+    float* rowc = reinterpret_cast<float*>(smem + 4 * TB);  // [2][64]: 32 lse2 | 32 delta
+
+    const int key0 = kvb * 128 + wave * 32;
+    const int key = key0 + (lane & 31);
+    const bool kvalid = key < S && (a.kmask == nullptr || a.kmask[rowbase + key] != 0);
+    bf16x8 kf[NKS], vf[NKS];
+    {
+        const size_t rr = (size_t)(key < S ? key : S - 1);
+        const bf16* ksrc = kp + rr * a.ld + 8 * hl;
+        const bf16* vsrc = vp + rr * a.ld + 8 * hl;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            kf[ks] = *reinterpret_cast<const bf16x8*>(ksrc + 16 * ks);
+            vf[ks] = *reinterpret_cast<const bf16x8*>(vsrc + 16 * ks);
+        }
+    }
+    f32x16 dk[NDT], dv[NDT];
+#pragma unroll
+    for (int i = 0; i < NDT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[i][r] = 0.f; dv[i][r] = 0.f; }
+    const float c = a.scale * LOG2E;
+
+    const int qt0 = CAUSAL ? (kvb * 128) / 32 : 0;
+    const int qt1 = (S + 31) / 32;
+
+    auto stage = [&](int qt, int buf) {
+        char* base = smem + buf * 2 * TB;
+        stage_rows<D, KIND_ROW, 32>(base, qp, a.ld, qt * 32, S, wave, lane);
+        stage_rows<D, KIND_ROW, 32>(base + TB, dop, a.lddo, qt * 32, S, wave, lane);
+        if (threadIdx.x < 32) {
+            const int qr = qt * 32 + threadIdx.x;
+            rowc[buf * 64 + threadIdx.x] = qr < S ? lsep[qr] * LOG2E : INFINITY;
+            rowc[buf * 64 + 32 + threadIdx.x] = qr < S ? dltp[qr] : 0.f;
+        }
+    };
+
+    if (qt0 < qt1) stage(qt0, 0);
+    for (int qt = qt0; qt < qt1; ++qt) {
+        const int cur = (qt - qt0) & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (qt + 1 < qt1) stage(qt + 1, cur ^ 1);
+        const bool active = !CAUSAL || (qt * 32 + 31 >= key0);
+        if (active) {
+            const MMU_LDS char* qtile = (const MMU_LDS char*)smem + cur * 2 * TB;
+            const MMU_LDS char* dotile = qtile + TB;
+            const MMU_LDS float* rc = (const MMU_LDS float*)(smem + 4 * TB) + cur * 64;
+            f32x16 s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+            // S[q][key] = Q K^T ; dP[q][key] = dO V^T   (A = tile rows, B = register fragments)
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const bf16x8 qa = row_frag<D, KIND_ROW>(qtile, 0, ks, lane);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], s, 0, 0, 0);
+            }
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const bf16x8 da = row_frag<D, KIND_ROW>(dotile, 0, ks, lane);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[ks], dp, 0, 0, 0);
+            }
+            const bool diag = CAUSAL && (qt * 32 < key0 + 31);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int ql = 8 * g + 4 * hl;  // local q row of reg 4g
+                const f32x4 l4 = *(const MMU_LDS f32x4*)(rc + ql);
+                const f32x4 d4 = *(const MMU_LDS f32x4*)(rc + 32 + ql);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float x = s[4 * g + j] * c - l4[j];
+                    bool ok = kvalid;
+                    if (diag && (key > qt * 32 + ql + j)) ok = false;
+                    const float p = ok ? fast_exp2(x) : 0.f;
+                    s[4 * g + j] = p;
+                    dp[4 * g + j] = p * (dp[4 * g + j] - d4[j]) * a.scale;
+                }
+            }
+            // dV^T[d][key] += dO^T[d][q] P[q][key] ; dK^T[d][key] += Q^T[d][q] dS[q][key]
+#pragma unroll
+            for (int sk = 0; sk < 2; ++sk) {
+                const bf16x8 pf = pack8(s, sk);
+                const bf16x8 dsf = pack8(dp, sk);
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) {
+                    const bf16x8 dot_ = tr_frag<D, KIND_ROW>(dotile, 0, sk, dt * 32, lane);
+                    dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dot_, pf, dv[dt], 0, 0, 0);
+                    const bf16x8 qt_ = tr_frag<D, KIND_ROW>(qtile, 0, sk, dt * 32, lane);
+                    dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt_, dsf, dk[dt], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (key < S) {
+        bf16* dkp = a.dk + (rowbase + key) * a.ldg + hh * D;
+        bf16* dvp = a.dv + (rowbase + key) * a.ldg + hh * D;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 t, u;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    t[j] = f2bf(dk[dt][4 * g + j]);
+                    u[j] = f2bf(dv[dt][4 * g + j]);
+                }
+                *reinterpret_cast<bf16x4*>(dkp + dt * 32 + 8 * g + 4 * hl) = t;
+                *reinterpret_cast<bf16x4*>(dvp + dt * 32 + 8 * g + 4 * hl) = u;
+            }
+    }
+}
+
+template <typename K>
+int set_lds(K kern, int bytes) {
+    hipError_t e =
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    return (int)e;
+}
+
+template <int D, bool CAUSAL>
+int launch_fwd(const AttnArgs& a, hipStream_t s) {
+    constexpr int LDS = 4 * 64 * D * 2 + 2 * 64 * 4;
+    static bool cfg = false;
+    if (!cfg) {
+        int e = set_lds(attn_fwd_kernel<D, CAUSAL>, LDS);
+        if (e) return e;
+        cfg = true;
+    }
+    hipLaunchKernelGGL((attn_fwd_kernel<D, CAUSAL>), dim3((a.S + 127) / 128, a.H, a.B), dim3(256), LDS, s, a);
+    MMU_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int D, bool CAUSAL>
+int launch_bwd(const AttnArgs& a, hipStream_t s) {
+    constexpr int LDS_DQ = 4 * 64 * D * 2 + 2 * 64 * 4;
+    constexpr int LDS_KV = 4 * 32 * D * 2 + 2 * 64 * 4;
+    static bool cfg = false;
+    if (!cfg) {
+        int e = set_lds(attn_bwd_dq_kernel<D, CAUSAL>, LDS_DQ);
+        if (e) return e;
+        e = set_lds(attn_bwd_dkdv_kernel<D, CAUSAL>, LDS_KV);
+        if (e) return e;
+        cfg = true;
+    }
+    const size_t nrh = (size_t)a.B * a.S * a.H;
+    hipLaunchKernelGGL((attn_delta_kernel<D>), dim3((unsigned)((nrh + 3) / 4)), dim3(256), 0, s, a.o, a.ldo, a.dout,
+                       a.lddo, const_cast<float*>(a.delta), a.B, a.S, a.H);
+    MMU_CHECK_LAUNCH();
+    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<D, CAUSAL>), dim3((a.S + 127) / 128, a.H, a.B), dim3(256), LDS_KV, s, a);
+    MMU_CHECK_LAUNCH();
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<D, CAUSAL>), dim3((a.S + 127) / 128, a.H, a.B), dim3(256), LDS_DQ, s, a);
+    MMU_CHECK_LAUNCH();
+    return 0;
+}
+
+bool attn_args_ok(const AttnArgs& a, int D) {
+    if (a.B <= 0 || a.S <= 0 || a.H <= 0) return false;
+    if ((a.ld & 7) || (a.ldo & 3)) return false;
+    if (((uintptr_t)a.q | (uintptr_t)a.k | (uintptr_t)a.v) & 15) return false;
+    if ((uintptr_t)a.o & 7) return false;
+    return D == 64 || D == 128;
+}
+
+}  // namespace
+
+// q/k/v: bf16 rows of `ld` elements, head h at column h*head_dim of each pointer; sequences are consecutive
+// blocks of S rows. o: [B*S][ldo]. lse: [B][H][S] fp32 (may be null for inference). kmask: [B][S] int32 or null.
+extern "C" int mmu_attn_fwd(const void* q, const void* k, const void* v, int ld, void* o, int ldo, float* lse,
+                            const int* kmask, int B, int S, int H, int head_dim, float scale, int causal,
+                            void* stream) {
+    AttnArgs a = {};
+    a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.ld = ld;
+    a.o = (bf16*)o; a.ldo = ldo; a.lse = lse; a.kmask = kmask;
+    a.B = B; a.S = S; a.H = H; a.scale = scale;
+    if (!attn_args_ok(a, head_dim)) return -1;
+    hipStream_t s = (hipStream_t)stream;
+    if (head_dim == 128) return causal ? launch_fwd<128, true>(a, s) : launch_fwd<128, false>(a, s);
+    return causal ? launch_fwd<64, true>(a, s) : launch_fwd<64, false>(a, s);
+}
+
+// Backward (head_dim 128 only): needs q,k,v,o,lse of the forward plus dout; writes dq,dk,dv (row stride ldg,
+// head h at column h*head_dim of each pointer) and uses delta [B][H][S] fp32 as workspace.
+extern "C" int mmu_attn_bwd(const void* q, const void* k, const void* v, int ld, const void* o, int ldo,
+                            const float* lse, const int* kmask, const void* dout, int lddo, float* delta, void* dq,
+                            void* dk, void* dv, int ldg, int B, int S, int H, int head_dim, float scale, int causal,
+                            void* stream) {
+    AttnArgs a = {};
+    a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.ld = ld;
+    a.o = (bf16*)const_cast<void*>(o); a.ldo = ldo; a.lse = const_cast<float*>(lse); a.kmask = kmask;
+    a.B = B; a.S = S; a.H = H; a.scale = scale;
+    a.dout = (const bf16*)dout; a.lddo = lddo; a.delta = delta;
+    a.dq = (bf16*)dq; a.dk = (bf16*)dk; a.dv = (bf16*)dv; a.ldg = ldg;
+    if (!attn_args_ok(a, head_dim) || head_dim != 128 || (lddo & 7) || (ldg & 3) || !lse || !delta) return -1;
+    if (((uintptr_t)dout & 15) || (((uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 7)) return -1;
+    hipStream_t s = (hipStream_t)stream;
+    return causal ? launch_bwd<128, true>(a, s) : launch_bwd<128, false>(a, s);
+}

@@ -1,0 +1,71 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of the forget/retain step.
+// Wave = 64 lanes everywhere; no other target is supported.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define MMU_LDS __attribute__((address_space(3)))
+#define MMU_GLOBAL __attribute__((address_space(1)))
+
+#define MMU_CHECK_LAUNCH()                      \
+    do {                                        \
+        hipError_t e__ = hipGetLastError();     \
+        if (e__ != hipSuccess) return (int)e__; \
+    } while (0)
+
+// 16 bytes of zeros: out-of-range tile chunks are redirected here so that LDS-DMA staging
+// zero-fills tails without a per-element branch in the main loop.
+static __device__ __attribute__((aligned(16))) const uint32_t mmu_zero16[4] = {0u, 0u, 0u, 0u};
+
+__device__ __forceinline__ float bf2f(bf16 x) { return (float)x; }
+__device__ __forceinline__ bf16 f2bf(float x) { return (bf16)x; }  // v_cvt_pk_bf16_f32: RNE, NaN-preserving
+
+// async global -> LDS, 16 B per lane; LDS destination = wave-uniform base + lane*16.
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const MMU_GLOBAL void*)gsrc, (MMU_LDS void*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// block-wide sum for blockDim.x == 64*NW; scratch must hold NW floats. All threads get the result.
+template <int NW>
+__device__ __forceinline__ float block_sum(float v, float* scratch) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    __syncthreads();
+    if (l == 0) scratch[w] = v;
+    __syncthreads();
+    float r = 0.f;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) r += scratch[i];
+    return r;
+}
+template <int NW>
+__device__ __forceinline__ float block_max(float v, float* scratch) {
+    v = wave_max(v);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    __syncthreads();
+    if (l == 0) scratch[w] = v;
+    __syncthreads();
+    float r = scratch[0];
+#pragma unroll
+    for (int i = 1; i < NW; ++i) r = fmaxf(r, scratch[i]);
+    return r;
+}

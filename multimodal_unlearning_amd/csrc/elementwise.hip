@@ -1,0 +1,701 @@
+// HBM-bound kernels of the LLaVA forward/backward for gfx950: RMSNorm, LayerNorm, RoPE, SwiGLU, GELU,
+// token-embedding gather / image-feature scatter (+ backward), CLIP patch im2col and embedding assembly.
+// These stand in for the elementwise ATen ops under transformers' LlavaForConditionalGeneration that
+// mm/trainer.py:180-433 `model(**inputs)` and its backward execute (SURVEY.md §8a rows K2,K4,K6,K7,K9,K12).
+// All loads/stores are 16-byte vectors (8 bf16 per lane); reductions use wave shuffles.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// RMSNorm (modeling_llama.py:53-67 in transformers): fp32 internals, y = w * bf16(x * rstd)
+// One wave per row; the row is held in registers (MAXCH chunks of 8 per lane -> d <= 512*MAXCH).
+// ------------------------------------------------------------------------------------------------
+template <int MAXCH>
+__global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w,
+                                                          bf16* __restrict__ y, float* __restrict__ rstd_out, int M,
+                                                          int d, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nch = d >> 3;
+    const bf16* xr = x + (size_t)row * d;
+    float v[MAXCH][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXCH; ++c) {
+        const int ch = c * 64 + lane;
+        if (ch < nch) {
+            const bf16x8 t = *reinterpret_cast<const bf16x8*>(xr + ch * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                v[c][j] = bf2f(t[j]);
+                ss += v[c][j] * v[c][j];
+            }
+        }
+    }
+    ss = wave_sum(ss);
+    const float rstd = rsqrtf(ss / (float)d + eps);
+    if (lane == 0 && rstd_out) rstd_out[row] = rstd;
+    bf16* yr = y + (size_t)row * d;
+#pragma unroll
+    for (int c = 0; c < MAXCH; ++c) {
+        const int ch = c * 64 + lane;
+        if (ch < nch) {
+            const bf16x8 wv = *reinterpret_cast<const bf16x8*>(w + ch * 8);
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = f2bf(bf2f(wv[j]) * bf2f(f2bf(v[c][j] * rstd)));
+            *reinterpret_cast<bf16x8*>(yr + ch * 8) = o;
+        }
+    }
+}
+
+// Backward: g = dy*w ; xh = x*rstd ; dx = rstd*(g - xh*mean(g*xh)) (+ dres) ; dw_partial[blk] += dy*xh.
+// Grid-stride over rows; each wave keeps its column partial sums in registers, the 4 waves of a block
+// are combined through LDS, and one fp32 partial row per block goes to `dw_part` [gridDim.x][d].
+template <int MAXCH>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x,
+                                                          const bf16* __restrict__ w, const float* __restrict__ rstd,
+                                                          const bf16* __restrict__ dres, bf16* __restrict__ dx,
+                                                          float* __restrict__ dw_part, int M, int d) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* red = reinterpret_cast<float*>(smem_raw);  // [4][d]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nch = d >> 3;
+    float dwacc[MAXCH][8];
+#pragma unroll
+    for (int c = 0; c < MAXCH; ++c)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dwacc[c][j] = 0.f;
+    float wv[MAXCH][8];
+#pragma unroll
+    for (int c = 0; c < MAXCH; ++c) {
+        const int ch = c * 64 + lane;
+        if (ch < nch) {
+            const bf16x8 t = *reinterpret_cast<const bf16x8*>(w + ch * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) wv[c][j] = bf2f(t[j]);
+        }
+    }
+    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+        const float rs = rstd[row];
+        const size_t off = (size_t)row * d;
+        float g[MAXCH][8], xh[MAXCH][8];
+        float dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXCH; ++c) {
+            const int ch = c * 64 + lane;
+            if (ch < nch) {
+                const bf16x8 tdy = *reinterpret_cast<const bf16x8*>(dy + off + ch * 8);
+                const bf16x8 tx = *reinterpret_cast<const bf16x8*>(x + off + ch * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float dyv = bf2f(tdy[j]);
+                    xh[c][j] = bf2f(tx[j]) * rs;
+                    g[c][j] = dyv * wv[c][j];
+                    dot += g[c][j] * xh[c][j];
+                    dwacc[c][j] += dyv * bf2f(f2bf(xh[c][j]));
+                }
+            }
+        }
+        dot = wave_sum(dot) / (float)d;
+#pragma unroll
+        for (int c = 0; c < MAXCH; ++c) {
+            const int ch = c * 64 + lane;
+            if (ch < nch) {
+                bf16x8 o;
+                if (dres) {
+                    const bf16x8 r = *reinterpret_cast<const bf16x8*>(dres + off + ch * 8);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = f2bf(rs * (g[c][j] - xh[c][j] * dot) + bf2f(r[j]));
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = f2bf(rs * (g[c][j] - xh[c][j] * dot));
+                }
+                *reinterpret_cast<bf16x8*>(dx + off + ch * 8) = o;
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < MAXCH; ++c) {
+        const int ch = c * 64 + lane;
+        if (ch < nch) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) red[wave * d + ch * 8 + j] = dwacc[c][j];
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < d; i += 256)
+        dw_part[(size_t)blockIdx.x * d + i] = red[i] + red[d + i] + red[2 * d + i] + red[3 * d + i];
+}
+
+// dst[j] (+)= sum_p part[p][j]  (column reduce of the per-block partials; bf16 destination)
+__global__ void colsum_partials_kernel(const float* __restrict__ part, int nparts, int d, bf16* __restrict__ dst,
+                                       int accumulate) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= d) return;
+    float s = 0.f;
+    for (int p = 0; p < nparts; ++p) s += part[(size_t)p * d + j];
+    if (accumulate) s += bf2f(dst[j]);
+    dst[j] = f2bf(s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm forward (CLIP, frozen): fp32 statistics, one rounding at the output. One wave per row.
+// Optional fused "CLIP embeddings" producer: row = (cls | patch) + position embedding.
+// ------------------------------------------------------------------------------------------------
+template <int MAXCH>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w,
+                                                            const bf16* __restrict__ b, bf16* __restrict__ y, int M,
+                                                            int d, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nch = d >> 3;
+    const bf16* xr = x + (size_t)row * d;
+    float v[MAXCH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXCH; ++c) {
+        const int ch = c * 64 + lane;
+        if (ch < nch) {
+            const bf16x8 t = *reinterpret_cast<const bf16x8*>(xr + ch * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                v[c][j] = bf2f(t[j]);
+                s += v[c][j];
+            }
+        }
+    }
+    const float mean = wave_sum(s) / (float)d;
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXCH; ++c) {
+        const int ch = c * 64 + lane;
+        if (ch < nch) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float t = v[c][j] - mean;
+                ss += t * t;
+            }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(ss) / (float)d + eps);
+    bf16* yr = y + (size_t)row * d;
+#pragma unroll
+    for (int c = 0; c < MAXCH; ++c) {
+        const int ch = c * 64 + lane;
+        if (ch < nch) {
+            const bf16x8 wv = *reinterpret_cast<const bf16x8*>(w + ch * 8);
+            const bf16x8 bv = *reinterpret_cast<const bf16x8*>(b + ch * 8);
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = f2bf((v[c][j] - mean) * rstd * bf2f(wv[j]) + bf2f(bv[j]));
+            *reinterpret_cast<bf16x8*>(yr + ch * 8) = o;
+        }
+    }
+}
+
+// CLIP embeddings (modeling_clip.py CLIPVisionEmbeddings): out[b,0]=cls+pos[0]; out[b,1+p]=patch[b,p]+pos[1+p]
+__global__ void clip_embed_kernel(const bf16* __restrict__ patch, const bf16* __restrict__ cls,
+                                  const bf16* __restrict__ pos, bf16* __restrict__ out, int B, int T, int d) {
+    const int nch = d >> 3;
+    const size_t total = (size_t)B * T * nch;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % nch);
+        const size_t row = i / nch;
+        const int t = (int)(row % T);
+        const int b = (int)(row / T);
+        const bf16x8 pv = *reinterpret_cast<const bf16x8*>(pos + (size_t)t * d + ch * 8);
+        bf16x8 src;
+        if (t == 0)
+            src = *reinterpret_cast<const bf16x8*>(cls + ch * 8);
+        else
+            src = *reinterpret_cast<const bf16x8*>(patch + ((size_t)b * (T - 1) + (t - 1)) * d + ch * 8);
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = f2bf(bf2f(src[j]) + bf2f(pv[j]));
+        *reinterpret_cast<bf16x8*>(out + row * d + ch * 8) = o;
+    }
+}
+
+// im2col for the stride=P, kernel=P patch conv: out[b*np + py*g + px][c*P*P + iy*P + ix] (zero-padded to Kpad)
+__global__ void im2col_patch_kernel(const float* __restrict__ pix, bf16* __restrict__ out, int B, int C, int H,
+                                    int P, int Kpad) {
+    const int g = H / P;
+    const int K = C * P * P;
+    const size_t total = (size_t)B * g * g * Kpad;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % Kpad);
+        const size_t row = i / Kpad;
+        float v = 0.f;
+        if (k < K) {
+            const int ix = k % P, iy = (k / P) % P, c = k / (P * P);
+            const int px = (int)(row % g), py = (int)((row / g) % g), b = (int)(row / ((size_t)g * g));
+            v = pix[(((size_t)b * C + c) * H + (py * P + iy)) * H + (px * P + ix)];
+        }
+        out[i] = f2bf(v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// RoPE on the fused qkv buffer [M][ld] (q heads at col 0, k heads at col k_off), rotate-half convention
+// (modeling_llama.py rotate_half / apply_rotary_pos_emb): bf16 products, bf16 sum, cos/sin tables in bf16.
+// inverse=1 applies the transpose rotation (backward).
+// ------------------------------------------------------------------------------------------------
+__global__ void rope_kernel(bf16* __restrict__ qkv, const int* __restrict__ pos_ids, const bf16* __restrict__ cos_t,
+                            const bf16* __restrict__ sin_t, int M, int ld, int n_heads_total, int head_dim,
+                            int k_off, int n_q_heads, int inverse) {
+    const int half = head_dim >> 1;
+    const int cph = half >> 3;  // 16-B chunks per half head
+    const size_t total = (size_t)M * n_heads_total * cph;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % cph);
+        const int h = (int)((i / cph) % n_heads_total);
+        const size_t row = i / ((size_t)cph * n_heads_total);
+        const int pos = pos_ids[row];
+        const int col = (h < n_q_heads ? h * head_dim : k_off + (h - n_q_heads) * head_dim) + ch * 8;
+        bf16* p1 = qkv + row * ld + col;
+        bf16* p2 = p1 + half;
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(p1);
+        const bf16x8 b = *reinterpret_cast<const bf16x8*>(p2);
+        const bf16x8 c = *reinterpret_cast<const bf16x8*>(cos_t + (size_t)pos * half + ch * 8);
+        const bf16x8 s = *reinterpret_cast<const bf16x8*>(sin_t + (size_t)pos * half + ch * 8);
+        bf16x8 o1, o2;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float af = bf2f(a[j]), bfv = bf2f(b[j]), cf = bf2f(c[j]);
+            const float sf = inverse ? -bf2f(s[j]) : bf2f(s[j]);
+            o1[j] = f2bf(bf2f(f2bf(af * cf)) + bf2f(f2bf(-bfv * sf)));
+            o2[j] = f2bf(bf2f(f2bf(bfv * cf)) + bf2f(f2bf(af * sf)));
+        }
+        *reinterpret_cast<bf16x8*>(p1) = o1;
+        *reinterpret_cast<bf16x8*>(p2) = o2;
+    }
+}
+
+// cos/sin tables [n_pos][head_dim/2] in bf16 (LlamaRotaryEmbedding: fp32 angle, then cast)
+__global__ void rope_table_kernel(bf16* __restrict__ cos_t, bf16* __restrict__ sin_t, int n_pos, int half,
+                                  float theta) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pos * half) return;
+    const int p = i / half, j = i % half;
+    const float inv_freq = 1.0f / powf(theta, (float)(2 * j) / (float)(2 * half));
+    const float ang = (float)p * inv_freq;
+    cos_t[i] = f2bf(cosf(ang));
+    sin_t[i] = f2bf(sinf(ang));
+}
+
+// ------------------------------------------------------------------------------------------------
+// SwiGLU: gu [M][2I] (gate | up)  ->  h = bf16(silu(gate)) * up   (modeling_llama.py LlamaMLP)
+// ------------------------------------------------------------------------------------------------
+__global__ void swiglu_fwd_kernel(const bf16* __restrict__ gu, bf16* __restrict__ h, int M, int I) {
+    const int nch = I >> 3;
+    const size_t total = (size_t)M * nch;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % nch);
+        const size_t row = i / nch;
+        const bf16x8 g = *reinterpret_cast<const bf16x8*>(gu + row * 2 * I + ch * 8);
+        const bf16x8 u = *reinterpret_cast<const bf16x8*>(gu + row * 2 * I + I + ch * 8);
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float gf = bf2f(g[j]);
+            const float act = gf / (1.0f + __expf(-gf));
+            o[j] = f2bf(bf2f(f2bf(act)) * bf2f(u[j]));
+        }
+        *reinterpret_cast<bf16x8*>(h + row * I + ch * 8) = o;
+    }
+}
+
+__global__ void swiglu_bwd_kernel(const bf16* __restrict__ gu, const bf16* __restrict__ dh, bf16* __restrict__ dgu,
+                                  int M, int I) {
+    const int nch = I >> 3;
+    const size_t total = (size_t)M * nch;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % nch);
+        const size_t row = i / nch;
+        const bf16x8 g = *reinterpret_cast<const bf16x8*>(gu + row * 2 * I + ch * 8);
+        const bf16x8 u = *reinterpret_cast<const bf16x8*>(gu + row * 2 * I + I + ch * 8);
+        const bf16x8 d = *reinterpret_cast<const bf16x8*>(dh + row * I + ch * 8);
+        bf16x8 og, ou;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float gf = bf2f(g[j]), uf = bf2f(u[j]), df = bf2f(d[j]);
+            const float sig = 1.0f / (1.0f + __expf(-gf));
+            const float act = gf * sig;
+            ou[j] = f2bf(df * bf2f(f2bf(act)));
+            og[j] = f2bf(df * uf * (sig * (1.0f + gf * (1.0f - sig))));
+        }
+        *reinterpret_cast<bf16x8*>(dgu + row * 2 * I + ch * 8) = og;
+        *reinterpret_cast<bf16x8*>(dgu + row * 2 * I + I + ch * 8) = ou;
+    }
+}
+
+// GELU (erf) forward / backward (LlavaMultiModalProjector act)
+__global__ void gelu_fwd_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, size_t n8) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + i * 8);
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float f = bf2f(v[j]);
+            o[j] = f2bf(0.5f * f * (1.0f + erff(f * 0.70710678118654752f)));
+        }
+        *reinterpret_cast<bf16x8*>(y + i * 8) = o;
+    }
+}
+__global__ void gelu_bwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy, bf16* __restrict__ dx,
+                                size_t n8) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + i * 8);
+        const bf16x8 g = *reinterpret_cast<const bf16x8*>(dy + i * 8);
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float f = bf2f(v[j]);
+            const float cdf = 0.5f * (1.0f + erff(f * 0.70710678118654752f));
+            const float pdf = 0.3989422804014327f * __expf(-0.5f * f * f);
+            o[j] = f2bf(bf2f(g[j]) * (cdf + f * pdf));
+        }
+        *reinterpret_cast<bf16x8*>(dx + i * 8) = o;
+    }
+}
+
+// out = a + b (bf16, 8-wide)
+__global__ void add_kernel(const bf16* __restrict__ a, const bf16* __restrict__ b, bf16* __restrict__ o, size_t n8) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+        const bf16x8 x = *reinterpret_cast<const bf16x8*>(a + i * 8);
+        const bf16x8 y = *reinterpret_cast<const bf16x8*>(b + i * 8);
+        bf16x8 r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = f2bf(bf2f(x[j]) + bf2f(y[j]));
+        *reinterpret_cast<bf16x8*>(o + i * 8) = r;
+    }
+}
+
+// column-sum of a bf16 matrix [M][d] into fp32 partials (bias gradients): block handles a row range.
+__global__ void colsum_bf16_kernel(const bf16* __restrict__ x, float* __restrict__ part, int M, int d,
+                                   int rows_per_block) {
+    const int r0 = blockIdx.y * rows_per_block;
+    const int r1 = min(M, r0 + rows_per_block);
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= d) return;
+    float s = 0.f;
+    for (int r = r0; r < r1; ++r) s += bf2f(x[(size_t)r * d + j]);
+    part[(size_t)blockIdx.y * d + j] = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Token embedding gather + image-feature scatter (modeling_llava.py:233-248 masked_scatter):
+// slot[r] = index of the image feature row for position r, or -1 for a text token.
+// ------------------------------------------------------------------------------------------------
+__global__ void image_slots_kernel(const long long* __restrict__ ids, int M, long long image_token,
+                                   int* __restrict__ slot, int* __restrict__ count) {
+    // single block; sequential chunked scan (M is a few thousand to ~1e5)
+    __shared__ int base;
+    __shared__ int wsum[16];
+    if (threadIdx.x == 0) base = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int start = 0; start < M; start += blockDim.x) {
+        const int r = start + threadIdx.x;
+        const int is_img = (r < M && ids[r] == image_token) ? 1 : 0;
+        const unsigned long long bal = __ballot(is_img);
+        const int prefix = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wave] = __popcll(bal);
+        __syncthreads();
+        int woff = 0;
+        for (int i = 0; i < wave; ++i) woff += wsum[i];
+        int tot = 0;
+        for (int i = 0; i < nw; ++i) tot += wsum[i];
+        if (r < M) slot[r] = is_img ? (base + woff + prefix) : -1;
+        __syncthreads();
+        if (threadIdx.x == 0) base += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *count = base;
+}
+
+__global__ void embed_fwd_kernel(const long long* __restrict__ ids, const int* __restrict__ slot,
+                                 const bf16* __restrict__ table, const bf16* __restrict__ img, bf16* __restrict__ out,
+                                 int M, int d, int vocab) {
+    const int nch = d >> 3;
+    const size_t total = (size_t)M * nch;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % nch);
+        const size_t row = i / nch;
+        const int s = slot ? slot[row] : -1;
+        bf16x8 v;
+        if (s >= 0) {
+            v = *reinterpret_cast<const bf16x8*>(img + (size_t)s * d + ch * 8);
+        } else {
+            long long id = ids[row];
+            id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+            v = *reinterpret_cast<const bf16x8*>(table + (size_t)id * d + ch * 8);
+        }
+        *reinterpret_cast<bf16x8*>(out + row * d + ch * 8) = v;
+    }
+}
+
+// Backward: image rows -> dimg[slot] = dh[row]; text rows -> fp32 atomicAdd into scratch[id] and flag[id]=1.
+__global__ void embed_bwd_kernel(const long long* __restrict__ ids, const int* __restrict__ slot,
+                                 const bf16* __restrict__ dh, bf16* __restrict__ dimg, float* __restrict__ scratch,
+                                 int* __restrict__ flag, int M, int d, int vocab) {
+    const int nch = d >> 3;
+    const size_t total = (size_t)M * nch;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % nch);
+        const size_t row = i / nch;
+        const int s = slot ? slot[row] : -1;
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(dh + row * d + ch * 8);
+        if (s >= 0) {
+            if (dimg) *reinterpret_cast<bf16x8*>(dimg + (size_t)s * d + ch * 8) = v;
+        } else if (scratch) {
+            long long id = ids[row];
+            id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+            float* dst = scratch + (size_t)id * d + ch * 8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) atomicAdd(dst + j, bf2f(v[j]));
+            if (ch == 0) flag[id] = 1;
+        }
+    }
+}
+
+// grad[v] += scratch[v] for flagged rows; scratch and flag are returned to zero.
+__global__ void embed_flush_kernel(float* __restrict__ scratch, int* __restrict__ flag, bf16* __restrict__ grad,
+                                   int vocab, int d) {
+    const int nch = d >> 3;
+    for (int v = blockIdx.x; v < vocab; v += gridDim.x) {
+        if (flag[v] == 0) continue;
+        for (int ch = threadIdx.x; ch < nch; ch += blockDim.x) {
+            float* sp = scratch + (size_t)v * d + ch * 8;
+            bf16* gp = grad + (size_t)v * d + ch * 8;
+            const bf16x8 g = *reinterpret_cast<const bf16x8*>(gp);
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                o[j] = f2bf(bf2f(g[j]) + sp[j]);
+                sp[j] = 0.f;
+            }
+            *reinterpret_cast<bf16x8*>(gp) = o;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) flag[v] = 0;
+    }
+}
+
+inline int grid_for(size_t work_items, int block) {
+    size_t g = (work_items + block - 1) / block;
+    if (g > 2048) g = 2048;  // 256 CUs x 8 blocks, grid-stride the rest
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+#define MMU_MAXCH_DISPATCH(d, CALL)          \
+    do {                                     \
+        if ((d) <= 1024) { CALL(2); }        \
+        else if ((d) <= 4096) { CALL(8); }   \
+        else if ((d) <= 8192) { CALL(16); }  \
+        else return -1;                      \
+    } while (0)
+
+extern "C" int mmu_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int M, int d, float eps,
+                               void* stream) {
+    if (M <= 0 || (d & 7)) return -1;
+    hipStream_t s = (hipStream_t)stream;
+#define CALL(N)                                                                                              \
+    hipLaunchKernelGGL(rmsnorm_fwd_kernel<N>, dim3((M + 3) / 4), dim3(256), 0, s, (const bf16*)x, (const bf16*)w, \
+                       (bf16*)y, rstd, M, d, eps)
+    MMU_MAXCH_DISPATCH(d, CALL);
+#undef CALL
+    MMU_CHECK_LAUNCH();
+    return 0;
+}
+
+// dw_part must hold mmu_rmsnorm_bwd_nparts(M) * d floats.
+extern "C" int mmu_rmsnorm_bwd_nparts(int M) {
+    int g = (M + 3) / 4;
+    return g > 256 ? 256 : (g < 1 ? 1 : g);
+}
+
+extern "C" int mmu_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres,
+                               void* dx, float* dw_part, void* dw, int accumulate_dw, int M, int d, void* stream) {
+    if (M <= 0 || (d & 7)) return -1;
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = mmu_rmsnorm_bwd_nparts(M);
+    const size_t lds = (size_t)4 * d * sizeof(float);
+#define CALL(N)                                                                                                   \
+    do {                                                                                                          \
+        static bool cfg = false;                                                                                  \
+        if (!cfg) {                                                                                               \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rmsnorm_bwd_kernel<N>),              \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 512 * N * 4);      \
+            if (e != hipSuccess) return (int)e;                                                                   \
+            cfg = true;                                                                                           \
+        }                                                                                                         \
+        hipLaunchKernelGGL(rmsnorm_bwd_kernel<N>, dim3(grid), dim3(256), lds, s, (const bf16*)dy, (const bf16*)x, \
+                           (const bf16*)w, rstd, (const bf16*)dres, (bf16*)dx, dw_part, M, d);                    \
+    } while (0)
+    MMU_MAXCH_DISPATCH(d, CALL);
+#undef CALL
+    MMU_CHECK_LAUNCH();
+    if (dw) {
+        hipLaunchKernelGGL(colsum_partials_kernel, dim3((d + 255) / 256), dim3(256), 0, s, dw_part, grid, d, (bf16*)dw,
+                           accumulate_dw);
+        MMU_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
+extern "C" int mmu_layernorm_fwd(const void* x, const void* w, const void* b, void* y, int M, int d, float eps,
+                                 void* stream) {
+    if (M <= 0 || (d & 7)) return -1;
+    hipStream_t s = (hipStream_t)stream;
+#define CALL(N)                                                                                                \
+    hipLaunchKernelGGL(layernorm_fwd_kernel<N>, dim3((M + 3) / 4), dim3(256), 0, s, (const bf16*)x, (const bf16*)w, \
+                       (const bf16*)b, (bf16*)y, M, d, eps)
+    MMU_MAXCH_DISPATCH(d, CALL);
+#undef CALL
+    MMU_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mmu_clip_embed(const void* patch, const void* cls, const void* pos, void* out, int B, int T, int d,
+                              void* stream) {
+    if (B <= 0 || T <= 1 || (d & 7)) return -1;
+    const size_t work = (size_t)B * T * (d >> 3);
+    hipLaunchKernelGGL(clip_embed_kernel, dim3(grid_for(work, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16*)patch, (const bf16*)cls, (const bf16*)pos, (bf16*)out, B, T, d);
+    MMU_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mmu_im2col_patch(const float* pix, void* out, int B, int C, int H, int P, int Kpad, void* stream) {
+    if (B <= 0 || H % P || Kpad < C * P * P || (Kpad & 7)) return -1;
+    const size_t work = (size_t)B * (H / P) * (H / P) * Kpad;
+    hipLaunchKernelGGL(im2col_patch_kernel, dim3(grid_for(work, 256)), dim3(256), 0, (hipStream_t)stream, pix,
+                       (bf16*)out, B, C, H, P, Kpad);
+    MMU_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mmu_rope(void* qkv, const int* pos_ids, const void* cos_t, const void* sin_t, int M, int ld,
+                        int n_q_heads, int n_k_heads, int head_dim, int k_off, int inverse, void* stream) {
+    if (M <= 0 || (head_dim & 15) || (ld & 7) || (k_off & 7)) return -1;
+    const int nh = n_q_heads + n_k_heads;
+    const size_t work = (size_t)M * nh * (head_dim >> 4);
+    hipLaunchKernelGGL(rope_kernel, dim3(grid_for(work, 256)), dim3(256), 0, (hipStream_t)stream, (bf16*)qkv, pos_ids,
+                       (const bf16*)cos_t, (const bf16*)sin_t, M, ld, nh, head_dim, k_off, n_q_heads, inverse);
+    MMU_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mmu_rope_table(void* cos_t, void* sin_t, int n_pos, int head_dim, float theta, void* stream) {
+    if (n_pos <= 0 || (head_dim & 15)) return -1;
+    const int half = head_dim / 2;
+    const int n = n_pos * half;
+    hipLaunchKernelGGL(rope_table_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (bf16*)cos_t,
+                       (bf16*)sin_t, n_pos, half, theta);
+    MMU_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mmu_swiglu_fwd(const void* gu, void* h, int M, int I, void* stream) {
+    if (M <= 0 || (I & 7)) return -1;
+    const size_t work = (size_t)M * (I >> 3);
+    hipLaunchKernelGGL(swiglu_fwd_kernel, dim3(grid_for(work, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16*)gu, (bf16*)h, M, I);
+    MMU_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mmu_swiglu_bwd(const void* gu, const void* dh, void* dgu, int M, int I, void* stream) {
+    if (M <= 0 || (I & 7)) return -1;
+    const size_t work = (size_t)M * (I >> 3);
+    hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(grid_for(work, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16*)gu, (const bf16*)dh, (bf16*)dgu, M, I);
+    MMU_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mmu_gelu_fwd(const void* x, void* y, long long n, void* stream) {
+    if (n <= 0 || (n & 7)) return -1;
+    hipLaunchKernelGGL(gelu_fwd_kernel, dim3(grid_for((size_t)n / 8, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16*)x, (bf16*)y, (size_t)n / 8);
+    MMU_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mmu_gelu_bwd(const void* x, const void* dy, void* dx, long long n, void* stream) {
+    if (n <= 0 || (n & 7)) return -1;
+    hipLaunchKernelGGL(gelu_bwd_kernel, dim3(grid_for((size_t)n / 8, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16*)x, (const bf16*)dy, (bf16*)dx, (size_t)n / 8);
+    MMU_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mmu_add_bf16(const void* a, const void* b, void* out, long long n, void* stream) {
+    if (n <= 0 || (n & 7)) return -1;
+    hipLaunchKernelGGL(add_kernel, dim3(grid_for((size_t)n / 8, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16*)a, (const bf16*)b, (bf16*)out, (size_t)n / 8);
+    MMU_CHECK_LAUNCH();
+    return 0;
+}
+
+// Bias gradient: dst[j] (+)= sum_r x[r][j]. part must hold mmu_colsum_nparts(M) * d floats.
+extern "C" int mmu_colsum_nparts(int M) {
+    int g = (M + 63) / 64;
+    return g < 1 ? 1 : g;
+}
+extern "C" int mmu_colsum_bf16(const void* x, float* part, void* dst, int accumulate, int M, int d, void* stream) {
+    if (M <= 0 || d <= 0) return -1;
+    hipStream_t s = (hipStream_t)stream;
+    const int nparts = mmu_colsum_nparts(M);
+    hipLaunchKernelGGL(colsum_bf16_kernel, dim3((d + 255) / 256, nparts), dim3(256), 0, s, (const bf16*)x, part, M, d,
+                       64);
+    MMU_CHECK_LAUNCH();
+    hipLaunchKernelGGL(colsum_partials_kernel, dim3((d + 255) / 256), dim3(256), 0, s, part, nparts, d, (bf16*)dst,
+                       accumulate);
+    MMU_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mmu_image_slots(const long long* ids, int M, long long image_token, int* slot, int* count,
+                               void* stream) {
+    if (M <= 0) return -1;
+    hipLaunchKernelGGL(image_slots_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, ids, M, image_token, slot,
+                       count);
+    MMU_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mmu_embed_fwd(const long long* ids, const int* slot, const void* table, const void* img, void* out,
+                             int M, int d, int vocab, void* stream) {
+    if (M <= 0 || (d & 7)) return -1;
+    const size_t work = (size_t)M * (d >> 3);
+    hipLaunchKernelGGL(embed_fwd_kernel, dim3(grid_for(work, 256)), dim3(256), 0, (hipStream_t)stream, ids, slot,
+                       (const bf16*)table, (const bf16*)img, (bf16*)out, M, d, vocab);
+    MMU_CHECK_LAUNCH();
+    return 0;
+}
+
+// scratch: [vocab][d] fp32, flag: [vocab] int32 — both must be zero on entry and are zero again on return
+// (when grad_table is given). dimg / grad_table may be null (frozen).
+extern "C" int mmu_embed_bwd(const long long* ids, const int* slot, const void* dh, void* dimg, float* scratch,
+                             int* flag, void* grad_table, int M, int d, int vocab, void* stream) {
+    if (M <= 0 || (d & 7)) return -1;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t work = (size_t)M * (d >> 3);
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid_for(work, 256)), dim3(256), 0, s, ids, slot, (const bf16*)dh,
+                       (bf16*)dimg, grad_table ? scratch : nullptr, flag, M, d, vocab);
+    MMU_CHECK_LAUNCH();
+    if (grad_table) {
+        hipLaunchKernelGGL(embed_flush_kernel, dim3(2048), dim3(256), 0, s, scratch, flag, (bf16*)grad_table, vocab, d);
+        MMU_CHECK_LAUNCH();
+    }
+    return 0;
+}

@@ -1,0 +1,323 @@
+"""ctypes binding of libmmu_hip.so (include/mmu_hip.h) + thin torch-tensor wrappers.
+
+PyTorch is used only for device memory and the current HIP stream; every wrapper launches a hand-written
+gfx950 kernel.  There is NO fallback: if the library is missing or a kernel rejects its arguments the
+call raises (the product path must fail loudly rather than run on an eager/CPU substitute).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmmu_hip.so")
+
+_vp, _i, _f, _ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
+
+# name -> argtypes (restype is always int).  Kept in one table so tests can check every exported symbol
+# of include/mmu_hip.h is bound.
+SIGNATURES = {
+    "mmu_abi_version": [],
+    "mmu_gemm_bf16": [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "mmu_attn_fwd": [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp],
+    "mmu_attn_bwd": [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i,
+                     _vp],
+    "mmu_rmsnorm_fwd": [_vp, _vp, _vp, _vp, _i, _i, _f, _vp],
+    "mmu_rmsnorm_bwd_nparts": [_i],
+    "mmu_rmsnorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "mmu_layernorm_fwd": [_vp, _vp, _vp, _vp, _i, _i, _f, _vp],
+    "mmu_im2col_patch": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "mmu_clip_embed": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "mmu_rope_table": [_vp, _vp, _i, _i, _f, _vp],
+    "mmu_rope": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "mmu_swiglu_fwd": [_vp, _vp, _i, _i, _vp],
+    "mmu_swiglu_bwd": [_vp, _vp, _vp, _i, _i, _vp],
+    "mmu_gelu_fwd": [_vp, _vp, _ll, _vp],
+    "mmu_gelu_bwd": [_vp, _vp, _vp, _ll, _vp],
+    "mmu_add_bf16": [_vp, _vp, _vp, _ll, _vp],
+    "mmu_colsum_nparts": [_i],
+    "mmu_colsum_bf16": [_vp, _vp, _vp, _i, _i, _i, _vp],
+    "mmu_image_slots": [_vp, _i, _ll, _vp, _vp, _vp],
+    "mmu_embed_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "mmu_embed_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "mmu_ce_fwd": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "mmu_ce_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp],
+    "mmu_seg_reduce": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp],
+    "mmu_rowloss_fwd": [_i, _vp, _vp, _i, _f, _vp, _i, _i, _vp],
+    "mmu_rowloss_bwd": [_i, _vp, _vp, _i, _f, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "mmu_sumsq_bf16": [_vp, _ll, _vp, _vp],
+    "mmu_adamw_bf16": [_vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _f, _i, _vp, _f, _f, _i, _vp],
+    "mmu_scale_bf16": [_vp, _ll, _f, _vp],
+}
+
+_lib = None
+
+
+class HipKernelError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load libmmu_hip.so; raises if it has not been built (python -m multimodal_unlearning_amd.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipKernelError(
+                f"{LIB_PATH} not found: build it with `python -m multimodal_unlearning_amd.build` "
+                "(hipcc --offload-arch=gfx950). There is no CPU / eager fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.argtypes = argtypes
+            fn.restype = C.c_int
+        _lib = lib
+    return _lib
+
+
+def _check(rc: int, name: str):
+    if rc != 0:
+        raise HipKernelError(f"{name} failed with code {rc}" + (" (unsupported argument)" if rc == -1 else " (hipError)"))
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _bf16c(*ts):
+    for t in ts:
+        if t is not None:
+            assert t.dtype == torch.bfloat16 and t.is_cuda, (t.dtype, t.device)
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+NT, NN, TN = 0, 1, 2
+ACT_NONE, ACT_GELU, ACT_QUICK_GELU = 0, 1, 2
+
+
+def gemm(layout: int, A, B, out, *, bias=None, resid=None, act=0, accumulate=False, M=None, N=None, K=None):
+    """out[M,N] = epi(Aop @ Bop^T).  2-D tensors with unit inner stride; leading dims taken from strides."""
+    _bf16c(A, B, out, bias, resid)
+    assert A.stride(-1) == 1 and B.stride(-1) == 1 and out.stride(-1) == 1
+    if layout == NT:
+        m, k = A.shape
+        n, k2 = B.shape
+    elif layout == NN:
+        m, k = A.shape
+        k2, n = B.shape
+    else:
+        k, m = A.shape
+        k2, n = B.shape
+    assert k == k2, (A.shape, B.shape, layout)
+    M = m if M is None else M
+    N = n if N is None else N
+    K = k if K is None else K
+    assert out.shape[0] >= M and out.shape[1] >= N
+    rc = load().mmu_gemm_bf16(layout, _p(A), _p(B), _p(out), _p(bias), _p(resid), M, N, K, A.stride(0), B.stride(0),
+                              out.stride(0), resid.stride(0) if resid is not None else 0, act, int(accumulate),
+                              _stream())
+    _check(rc, "mmu_gemm_bf16")
+    return out
+
+
+# ------------------------------------------------------------------------------------------- attention
+def attn_fwd(q, k, v, out, lse, kmask, B, S, H, head_dim, scale, causal):
+    """q/k/v: 2-D views [B*S, H*head_dim] (row stride = ld, e.g. slices of a fused qkv buffer)."""
+    _bf16c(q, k, v, out)
+    assert q.stride(0) == k.stride(0) == v.stride(0) and q.stride(1) == 1
+    rc = load().mmu_attn_fwd(_p(q), _p(k), _p(v), q.stride(0), _p(out), out.stride(0), _p(lse), _p(kmask), B, S, H,
+                             head_dim, float(scale), int(causal), _stream())
+    _check(rc, "mmu_attn_fwd")
+    return out
+
+
+def attn_bwd(q, k, v, o, lse, kmask, dout, delta, dq, dk, dv, B, S, H, head_dim, scale, causal):
+    _bf16c(q, k, v, o, dout, dq, dk, dv)
+    assert dq.stride(0) == dk.stride(0) == dv.stride(0)
+    rc = load().mmu_attn_bwd(_p(q), _p(k), _p(v), q.stride(0), _p(o), o.stride(0), _p(lse), _p(kmask), _p(dout),
+                             dout.stride(0), _p(delta), _p(dq), _p(dk), _p(dv), dq.stride(0), B, S, H, head_dim,
+                             float(scale), int(causal), _stream())
+    _check(rc, "mmu_attn_bwd")
+
+
+# ------------------------------------------------------------------------------------------------ norms
+def rmsnorm_fwd(x, w, y, rstd, eps):
+    _bf16c(x, w, y)
+    M, d = x.shape
+    _check(load().mmu_rmsnorm_fwd(_p(x), _p(w), _p(y), _p(rstd), M, d, float(eps), _stream()), "mmu_rmsnorm_fwd")
+    return y
+
+
+def rmsnorm_bwd_nparts(M):
+    return load().mmu_rmsnorm_bwd_nparts(M)
+
+
+def rmsnorm_bwd(dy, x, w, rstd, dres, dx, dw_part, dw, accumulate_dw):
+    _bf16c(dy, x, w, dres, dx, dw)
+    M, d = x.shape
+    _check(load().mmu_rmsnorm_bwd(_p(dy), _p(x), _p(w), _p(rstd), _p(dres), _p(dx), _p(dw_part), _p(dw),
+                                  int(accumulate_dw), M, d, _stream()), "mmu_rmsnorm_bwd")
+    return dx
+
+
+def layernorm_fwd(x, w, b, y, eps):
+    _bf16c(x, w, b, y)
+    M, d = x.shape
+    _check(load().mmu_layernorm_fwd(_p(x), _p(w), _p(b), _p(y), M, d, float(eps), _stream()), "mmu_layernorm_fwd")
+    return y
+
+
+def im2col_patch(pix, out, P):
+    assert pix.dtype == torch.float32 and pix.is_cuda and pix.is_contiguous()
+    B, Cc, Hh, Ww = pix.shape
+    assert Hh == Ww
+    _check(load().mmu_im2col_patch(_p(pix), _p(out), B, Cc, Hh, P, out.shape[1], _stream()), "mmu_im2col_patch")
+    return out
+
+
+def clip_embed(patch, cls, pos, out, B, T, d):
+    _bf16c(patch, cls, pos, out)
+    _check(load().mmu_clip_embed(_p(patch), _p(cls), _p(pos), _p(out), B, T, d, _stream()), "mmu_clip_embed")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------- rope
+def rope_table(cos_t, sin_t, n_pos, head_dim, theta):
+    _bf16c(cos_t, sin_t)
+    _check(load().mmu_rope_table(_p(cos_t), _p(sin_t), n_pos, head_dim, float(theta), _stream()), "mmu_rope_table")
+
+
+def rope(qkv, pos_ids, cos_t, sin_t, n_q_heads, n_k_heads, head_dim, k_off, inverse=False):
+    _bf16c(qkv, cos_t, sin_t)
+    assert pos_ids.dtype == torch.int32
+    M = qkv.shape[0]
+    _check(load().mmu_rope(_p(qkv), _p(pos_ids), _p(cos_t), _p(sin_t), M, qkv.stride(0), n_q_heads, n_k_heads,
+                           head_dim, k_off, int(inverse), _stream()), "mmu_rope")
+    return qkv
+
+
+# ------------------------------------------------------------------------------------ swiglu / gelu / add
+def swiglu_fwd(gu, h):
+    _bf16c(gu, h)
+    M, I2 = gu.shape
+    _check(load().mmu_swiglu_fwd(_p(gu), _p(h), M, I2 // 2, _stream()), "mmu_swiglu_fwd")
+    return h
+
+
+def swiglu_bwd(gu, dh, dgu):
+    _bf16c(gu, dh, dgu)
+    M, I2 = gu.shape
+    _check(load().mmu_swiglu_bwd(_p(gu), _p(dh), _p(dgu), M, I2 // 2, _stream()), "mmu_swiglu_bwd")
+    return dgu
+
+
+def gelu_fwd(x, y):
+    _bf16c(x, y)
+    _check(load().mmu_gelu_fwd(_p(x), _p(y), x.numel(), _stream()), "mmu_gelu_fwd")
+    return y
+
+
+def gelu_bwd(x, dy, dx):
+    _bf16c(x, dy, dx)
+    _check(load().mmu_gelu_bwd(_p(x), _p(dy), _p(dx), x.numel(), _stream()), "mmu_gelu_bwd")
+    return dx
+
+
+def add(a, b, out):
+    _bf16c(a, b, out)
+    _check(load().mmu_add_bf16(_p(a), _p(b), _p(out), a.numel(), _stream()), "mmu_add_bf16")
+    return out
+
+
+def colsum_nparts(M):
+    return load().mmu_colsum_nparts(M)
+
+
+def colsum(x, part, dst, accumulate):
+    _bf16c(x, dst)
+    M, d = x.shape
+    _check(load().mmu_colsum_bf16(_p(x), _p(part), _p(dst), int(accumulate), M, d, _stream()), "mmu_colsum_bf16")
+    return dst
+
+
+# -------------------------------------------------------------------------------------------- embedding
+def image_slots(ids, image_token, slot, count):
+    assert ids.dtype == torch.int64 and ids.is_contiguous()
+    _check(load().mmu_image_slots(_p(ids), ids.numel(), int(image_token), _p(slot), _p(count), _stream()),
+           "mmu_image_slots")
+
+
+def embed_fwd(ids, slot, table, img, out):
+    _bf16c(table, img, out)
+    M, d = out.shape
+    _check(load().mmu_embed_fwd(_p(ids), _p(slot), _p(table), _p(img), _p(out), M, d, table.shape[0], _stream()),
+           "mmu_embed_fwd")
+    return out
+
+
+def embed_bwd(ids, slot, dh, dimg, scratch, flag, grad_table, vocab):
+    _bf16c(dh, dimg, grad_table)
+    M, d = dh.shape
+    _check(load().mmu_embed_bwd(_p(ids), _p(slot), _p(dh), _p(dimg), _p(scratch), _p(flag), _p(grad_table), M, d,
+                                vocab, _stream()), "mmu_embed_bwd")
+
+
+# ----------------------------------------------------------------------------------------------- losses
+def ce_fwd(logits, labels, lse, loss_row, S, shift=True):
+    _bf16c(logits)
+    M, V = logits.shape
+    _check(load().mmu_ce_fwd(_p(logits), logits.stride(0), _p(labels), _p(lse), _p(loss_row), M, V, S, int(shift),
+                             _stream()), "mmu_ce_fwd")
+
+
+def ce_bwd(logits, labels, lse, seg_scale, seg_cnt, seg_rows, normalize, dlogits, S, shift=True):
+    _bf16c(logits, dlogits)
+    M, V = logits.shape
+    _check(load().mmu_ce_bwd(_p(logits), logits.stride(0), _p(labels), _p(lse), _p(seg_scale), _p(seg_cnt), seg_rows,
+                             int(normalize), _p(dlogits), dlogits.stride(0), M, V, S, int(shift), _stream()),
+           "mmu_ce_bwd")
+
+
+def seg_reduce(vals, labels, seg_rows, M, V, S, shift, out_sum, out_cnt):
+    _check(load().mmu_seg_reduce(_p(vals), _p(labels), seg_rows, M, V, S, int(shift), _p(out_sum), _p(out_cnt),
+                                 _stream()), "mmu_seg_reduce")
+
+
+KL_STUDENT_INPUT, KL_TEACHER_INPUT, NPO, ENTROPY = 0, 1, 2, 3
+
+
+def rowloss_fwd(mode, slog, tlog, beta, stats):
+    _bf16c(slog, tlog)
+    M, V = slog.shape
+    _check(load().mmu_rowloss_fwd(mode, _p(slog), _p(tlog), slog.stride(0), float(beta), _p(stats), M, V, _stream()),
+           "mmu_rowloss_fwd")
+
+
+def rowloss_bwd(mode, slog, tlog, beta, stats, coef, dlogits):
+    _bf16c(slog, tlog, dlogits)
+    M, V = slog.shape
+    _check(load().mmu_rowloss_bwd(mode, _p(slog), _p(tlog), slog.stride(0), float(beta), _p(stats), _p(coef),
+                                  _p(dlogits), dlogits.stride(0), M, V, _stream()), "mmu_rowloss_bwd")
+
+
+# ---------------------------------------------------------------------------------------------- optimiser
+def sumsq(g, out):
+    _bf16c(g)
+    _check(load().mmu_sumsq_bf16(_p(g), g.numel(), _p(out), _stream()), "mmu_sumsq_bf16")
+
+
+def adamw(p, g, m, v, lr, beta1, beta2, eps, wd, step, sumsq_t, max_norm, grad_scale=1.0, zero_grad=True):
+    _bf16c(p, g)
+    _check(load().mmu_adamw_bf16(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, wd, step,
+                                 _p(sumsq_t), float(max_norm), float(grad_scale), int(zero_grad), _stream()),
+           "mmu_adamw_bf16")
+
+
+def scale_(x, s):
+    _bf16c(x)
+    _check(load().mmu_scale_bf16(_p(x), x.numel(), float(s), _stream()), "mmu_scale_bf16")

@@ -1,0 +1,36 @@
+"""CPU-side checks of the drop-in boundary: libmmu_hip.so loads and exports exactly include/mmu_hip.h."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    txt = open(os.path.join(ROOT, "include", "mmu_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\bint\s+(mmu_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from multimodal_unlearning_amd import build, hip
+
+    build.build(verbose=False)
+    lib = ctypes.CDLL(hip.LIB_PATH)
+    syms = _header_symbols()
+    assert len(syms) >= 30
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/mmu_hip.h but not exported"
+    assert sorted(hip.SIGNATURES) == syms, set(hip.SIGNATURES) ^ set(syms)
+    assert lib.mmu_abi_version() == 1
+
+
+def test_header_arity_matches_binding():
+    from multimodal_unlearning_amd import hip
+
+    txt = open(os.path.join(ROOT, "include", "mmu_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    for name, args in re.findall(r"\bint\s+(mmu_[a-z0-9_]+)\s*\(([^)]*)\)", txt):
+        args = args.strip()
+        n = 0 if args in ("", "void") else len(args.split(","))
+        assert n == len(hip.SIGNATURES[name]), (name, n, len(hip.SIGNATURES[name]))
