@@ -25,8 +25,14 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 // zero-fills tails without a per-element branch in the main loop.
 static __device__ __attribute__((aligned(16))) const uint32_t mmu_zero16[4] = {0u, 0u, 0u, 0u};
 
-__device__ __forceinline__ float bf2f(bf16 x) { return (float)x; }
+// bf16 <-> f32 through the bit pattern.  A plain `(float)(bf16)x` round trip is NOT used for intermediate
+// roundings: clang keeps bf16 expressions in excess (f32) precision and elides the rounding, which changes
+// results where the reference rounds every bf16 tensor op (measured on gfx950: RoPE off by 1 ulp).
+__device__ __forceinline__ float bf2f(bf16 x) {
+    return __uint_as_float(((uint32_t)__builtin_bit_cast(unsigned short, x)) << 16);
+}
 __device__ __forceinline__ bf16 f2bf(float x) { return (bf16)x; }  // v_cvt_pk_bf16_f32: RNE, NaN-preserving
+__device__ __forceinline__ float round_bf16(float x) { return bf2f((bf16)x); }
 
 // async global -> LDS, 16 B per lane; LDS destination = wave-uniform base + lane*16.
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {

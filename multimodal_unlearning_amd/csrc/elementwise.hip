@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16* __restrict
             const bf16x8 wv = *reinterpret_cast<const bf16x8*>(w + ch * 8);
             bf16x8 o;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = f2bf(bf2f(wv[j]) * bf2f(f2bf(v[c][j] * rstd)));
+            for (int j = 0; j < 8; ++j) o[j] = f2bf(bf2f(wv[j]) * round_bf16((v[c][j] * rstd)));
             *reinterpret_cast<bf16x8*>(yr + ch * 8) = o;
         }
     }
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16* __restrict
                     xh[c][j] = bf2f(tx[j]) * rs;
                     g[c][j] = dyv * wv[c][j];
                     dot += g[c][j] * xh[c][j];
-                    dwacc[c][j] += dyv * bf2f(f2bf(xh[c][j]));
+                    dwacc[c][j] += dyv * round_bf16((xh[c][j]));
                 }
             }
         }
@@ -267,8 +267,8 @@ __global__ void rope_kernel(bf16* __restrict__ qkv, const int* __restrict__ pos_
         for (int j = 0; j < 8; ++j) {
             const float af = bf2f(a[j]), bfv = bf2f(b[j]), cf = bf2f(c[j]);
             const float sf = inverse ? -bf2f(s[j]) : bf2f(s[j]);
-            o1[j] = f2bf(bf2f(f2bf(af * cf)) + bf2f(f2bf(-bfv * sf)));
-            o2[j] = f2bf(bf2f(f2bf(bfv * cf)) + bf2f(f2bf(af * sf)));
+            o1[j] = f2bf(round_bf16((af * cf)) + round_bf16((-bfv * sf)));
+            o2[j] = f2bf(round_bf16((bfv * cf)) + round_bf16((af * sf)));
         }
         *reinterpret_cast<bf16x8*>(p1) = o1;
         *reinterpret_cast<bf16x8*>(p2) = o2;
@@ -303,7 +303,7 @@ __global__ void swiglu_fwd_kernel(const bf16* __restrict__ gu, bf16* __restrict_
         for (int j = 0; j < 8; ++j) {
             const float gf = bf2f(g[j]);
             const float act = gf / (1.0f + __expf(-gf));
-            o[j] = f2bf(bf2f(f2bf(act)) * bf2f(u[j]));
+            o[j] = f2bf(round_bf16((act)) * bf2f(u[j]));
         }
         *reinterpret_cast<bf16x8*>(h + row * I + ch * 8) = o;
     }
@@ -325,7 +325,7 @@ __global__ void swiglu_bwd_kernel(const bf16* __restrict__ gu, const bf16* __res
             const float gf = bf2f(g[j]), uf = bf2f(u[j]), df = bf2f(d[j]);
             const float sig = 1.0f / (1.0f + __expf(-gf));
             const float act = gf * sig;
-            ou[j] = f2bf(df * bf2f(f2bf(act)));
+            ou[j] = f2bf(df * round_bf16((act)));
             og[j] = f2bf(df * uf * (sig * (1.0f + gf * (1.0f - sig))));
         }
         *reinterpret_cast<bf16x8*>(dgu + row * 2 * I + ch * 8) = og;

@@ -174,10 +174,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
                 }
                 // HF rounds the Linear output to bf16 before the activation / residual add; keep that order.
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = bf2f(f2bf(o[j]));
+                for (int j = 0; j < 4; ++j) o[j] = round_bf16((o[j]));
                 if (p.act) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = bf2f(f2bf(act_apply(o[j], p.act)));
+                    for (int j = 0; j < 4; ++j) o[j] = round_bf16((act_apply(o[j], p.act)));
                 }
                 if (p.resid) {
                     const bf16x4 r = *reinterpret_cast<const bf16x4*>(p.resid + (size_t)m * p.ldr + n);

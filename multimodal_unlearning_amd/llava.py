@@ -1,0 +1,464 @@
+"""LLaVA-1.5 forward + backward on the hand-written gfx950 kernels (libmmu_hip.so).
+
+This is the `model(**inputs)` that the reference's MMTrainerForgetting.compute_loss calls
+(mm/trainer.py:180-433): it returns an object with `.loss` (HF shifted CE, mean over supervised tokens)
+and `.logits`, attached to autograd so `loss.backward()` fills the gradients.  PyTorch supplies device
+memory, the stream and the autograd edge; every arithmetic step is a C-ABI kernel launch:
+
+  CLIP tower (frozen): im2col -> patch GEMM -> cls/pos -> pre-LN -> [LN, qkv GEMM+bias, attention(64, full),
+      out GEMM+bias+residual, LN, fc1 GEMM+bias+quick_gelu, fc2 GEMM+bias+residual] x (L-1) -> drop CLS
+  projector: GEMM+bias -> GELU -> GEMM+bias;  token gather + image-feature scatter
+  Llama decoder: [RMSNorm, fused qkv GEMM, RoPE in place, causal attention(128), o GEMM+residual, RMSNorm,
+      fused gate|up GEMM, SwiGLU, down GEMM+residual] x L -> RMSNorm -> lm_head GEMM -> bf16 logits
+  backward: explicit reverse sweep (dgrad = NN GEMM, wgrad = TN GEMM accumulating straight into the flat bf16
+      gradient buffer), RMSNorm / SwiGLU / RoPE / attention backward kernels, embedding scatter-add.
+
+Memory layout (MI355X, 288 GB): all trainable parameters live in ONE flat bf16 buffer (`train_flat`, a single
+nn.Parameter; projector then decoder, layer by layer) with ONE flat bf16 gradient buffer of the same shape —
+the AdamW kernel, the grad-norm kernel and the RCCL all-reduce each see a few large contiguous ranges.
+Frozen CLIP weights live in `frozen_flat`.  Activations are [tokens, features] row-major bf16; q/k/v stay
+fused in one [tokens, 3*H*D] buffer that the attention kernels index by head (no transposes anywhere).
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from typing import Callable, Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from . import hip
+from .config import LlavaConfig
+from .params import init_params, is_vision, param_specs
+
+BF = torch.bfloat16
+
+
+class LlavaOutput:
+    """Attribute + key access like transformers' ModelOutput (`.loss`, `.logits`)."""
+
+    def __init__(self, loss=None, logits=None, hidden_states=None):
+        self.loss, self.logits, self.hidden_states = loss, logits, hidden_states
+
+    def __getitem__(self, k):
+        return getattr(self, k)
+
+
+def _align8(n):
+    return (n + 7) // 8 * 8
+
+
+# --------------------------------------------------------------------------------------------------------
+# loss autograd functions (kernels in csrc/loss.hip)
+# --------------------------------------------------------------------------------------------------------
+class _SegCE(torch.autograd.Function):
+    """HF ForCausalLMLoss per segment of rows: out[seg] = mean over valid shifted targets of CE (or the SUM when
+    normalize=False, as get_batch_loss needs).  logits2d [M,V] bf16, labels [M] int64 (unshifted), S = seq len."""
+
+    @staticmethod
+    def forward(ctx, logits2d, labels, S, seg_rows, normalize):
+        M, V = logits2d.shape
+        dev = logits2d.device
+        lse = torch.empty(M, device=dev, dtype=torch.float32)
+        lrow = torch.empty(M, device=dev, dtype=torch.float32)
+        hip.ce_fwd(logits2d, labels, lse, lrow, S, shift=True)
+        nseg = (M + seg_rows - 1) // seg_rows
+        sums = torch.empty(nseg, device=dev, dtype=torch.float32)
+        cnts = torch.empty(nseg, device=dev, dtype=torch.float32)
+        hip.seg_reduce(lrow, labels, seg_rows, M, V, S, True, sums, cnts)
+        ctx.save_for_backward(logits2d, labels, lse, cnts)
+        ctx.meta = (S, seg_rows, normalize)
+        return sums / cnts.clamp(min=1.0) if normalize else sums
+
+    @staticmethod
+    def backward(ctx, g):
+        logits2d, labels, lse, cnts = ctx.saved_tensors
+        S, seg_rows, normalize = ctx.meta
+        dl = torch.empty_like(logits2d)
+        hip.ce_bwd(logits2d, labels, lse, g.contiguous().float(), cnts, seg_rows, normalize, dl, S, shift=True)
+        return dl, None, None, None, None
+
+
+class _RowLoss(torch.autograd.Function):
+    """sum over rows of a dual-logit row loss (mode: hip.KL_STUDENT_INPUT / KL_TEACHER_INPUT / NPO / ENTROPY)."""
+
+    @staticmethod
+    def forward(ctx, slog, tlog, mode, beta):
+        M, V = slog.shape
+        stats = torch.empty(M, 4, device=slog.device, dtype=torch.float32)
+        hip.rowloss_fwd(mode, slog, tlog, beta, stats)
+        out = torch.empty(1, device=slog.device, dtype=torch.float32)
+        # row values sit at stride 4 in `stats`; reduce them with the segment kernel on a compact copy
+        vals = stats[:, 2].contiguous()
+        hip.seg_reduce(vals, None, M, M, V, 1, False, out, None)
+        ctx.save_for_backward(slog, tlog, stats)
+        ctx.meta = (mode, beta)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        slog, tlog, stats = ctx.saved_tensors
+        mode, beta = ctx.meta
+        dl = torch.empty_like(slog)
+        hip.rowloss_bwd(mode, slog, tlog, beta, stats, g.reshape(1).float().contiguous(), dl)
+        return dl, None, None, None
+
+
+def causal_lm_loss(logits, labels):
+    """`outputs.loss` of the HF model: logits [B,S,V] bf16, labels [B,S] int64 -> 0-dim fp32."""
+    B, S, V = logits.shape
+    return _SegCE.apply(logits.view(B * S, V), labels.reshape(-1).contiguous(), S, B * S, True)[0]
+
+
+def segment_ce_losses(logits, labels, n_segments):
+    """Per-split mean CE for a batch that concatenates `n_segments` equal splits along dim 0 (paired fusion)."""
+    B, S, V = logits.shape
+    assert B % n_segments == 0
+    return _SegCE.apply(logits.view(B * S, V), labels.reshape(-1).contiguous(), S, (B // n_segments) * S, True)
+
+
+def sequence_ce_sums(logits, labels):
+    """mm/trainer_utils.py:73-81 get_batch_loss: per-sequence SUM of shifted CE -> [B]."""
+    B, S, V = logits.shape
+    return _SegCE.apply(logits.view(B * S, V), labels.reshape(-1).contiguous(), S, S, False)
+
+
+def row_loss_sum(student_logits, teacher_logits, mode, beta=1.0):
+    V = student_logits.shape[-1]
+    s2 = student_logits.reshape(-1, V)
+    t2 = None if teacher_logits is None else teacher_logits.reshape(-1, V)
+    return _RowLoss.apply(s2, t2, mode, float(beta))
+
+
+# --------------------------------------------------------------------------------------------------------
+# the model
+# --------------------------------------------------------------------------------------------------------
+class LlavaHIP(nn.Module):
+    def __init__(self, cfg: LlavaConfig, params: Optional[Dict[str, torch.Tensor]] = None, device="cuda:0",
+                 seed: int = 0, freeze_vision: bool = True, trainable: bool = True):
+        super().__init__()
+        if not freeze_vision:
+            raise NotImplementedError("the vision tower is frozen in the forget step (mm/forget.py:117-118)")
+        hip.load()  # fail loudly if the HIP library is missing
+        self.cfg = cfg
+        self.config = cfg  # HF-style alias (reference reads model.config.image_token_index)
+        dev = torch.device(device)
+        specs = param_specs(cfg)
+        self._specs = specs
+        # flat layout
+        self._off: Dict[str, tuple] = {}
+        nv = nt = 0
+        for name, shape in specs.items():
+            n = _align8(math.prod(shape))
+            if is_vision(name):
+                self._off[name] = ("v", nv, shape)
+                nv += n
+            else:
+                self._off[name] = ("t", nt, shape)
+                nt += n
+        self.register_buffer("frozen_flat", torch.zeros(nv, device=dev, dtype=BF), persistent=True)
+        self.train_flat = nn.Parameter(torch.zeros(nt, device=dev, dtype=BF), requires_grad=trainable)
+        self.w: Dict[str, torch.Tensor] = OrderedDict()
+        for name, (kind, off, shape) in self._off.items():
+            base = self.frozen_flat if kind == "v" else self.train_flat.data
+            self.w[name] = base[off:off + math.prod(shape)].view(shape)
+        self._grad_flat: Optional[torch.Tensor] = None
+        self.g: Dict[str, torch.Tensor] = OrderedDict()
+        if params is None:
+            params = init_params(cfg, seed=seed)
+        self.load_params(params)
+        # rope tables + scratch
+        t = cfg.text
+        self._cos = torch.empty(t.max_position, t.head_dim // 2, device=dev, dtype=BF)
+        self._sin = torch.empty_like(self._cos)
+        hip.rope_table(self._cos, self._sin, t.max_position, t.head_dim, t.rope_theta)
+        self._embed_scratch = None
+        self._embed_flag = None
+        # hook: called as fn(lo, hi) with the [lo,hi) element range of the flat gradient that is final for this
+        # backward (used by the DP engine to start the RCCL all-reduce of a bucket while backward continues)
+        self.grad_ready_hook: Optional[Callable[[int, int], None]] = None
+        self.capture_layer: Optional[int] = None
+
+    # ------------------------------------------------------------------------------------------ params
+    @property
+    def device(self):
+        return self.train_flat.device
+
+    def load_params(self, params: Dict[str, torch.Tensor]):
+        with torch.no_grad():
+            for name in self._specs:
+                self.w[name].copy_(params[name].to(self.device, dtype=BF))
+
+    def export_params(self) -> "OrderedDict[str, torch.Tensor]":
+        return OrderedDict((k, v.detach().float().cpu()) for k, v in self.w.items())
+
+    def trainable_names(self):
+        return [n for n in self._specs if not is_vision(n)]
+
+    def range_of(self, name):
+        kind, off, shape = self._off[name]
+        return off, off + _align8(math.prod(shape))
+
+    def layer_grad_range(self, i: int):
+        lo = self._off[f"text.layers.{i}.input_norm.weight"][1]
+        hi = self.range_of(f"text.layers.{i}.down.weight")[1]
+        return lo, hi
+
+    def ensure_grad(self):
+        """Attach the persistent flat gradient buffer as train_flat.grad (zeroed when (re)attached)."""
+        if self._grad_flat is None:
+            self._grad_flat = torch.zeros_like(self.train_flat.data)
+        if self.train_flat.grad is None or self.train_flat.grad.data_ptr() != self._grad_flat.data_ptr():
+            self._grad_flat.zero_()
+            self.train_flat.grad = self._grad_flat
+        if not self.g:
+            for name, (kind, off, shape) in self._off.items():
+                if kind == "t":
+                    self.g[name] = self._grad_flat[off:off + math.prod(shape)].view(shape)
+        return self._grad_flat
+
+    # ----------------------------------------------------------------------------------------- forward
+    def forward(self, input_ids=None, attention_mask=None, pixel_values=None, labels=None, position_ids=None,
+                **_unused):
+        logits = self.logits(input_ids, attention_mask, pixel_values, position_ids)
+        loss = None
+        if labels is not None:
+            loss = causal_lm_loss(logits, labels.to(logits.device))
+        hs = None
+        if self.capture_layer is not None:
+            hs = self._last_capture
+        return LlavaOutput(loss=loss, logits=logits, hidden_states=hs)
+
+    def logits(self, input_ids, attention_mask=None, pixel_values=None, position_ids=None):
+        dev = self.device
+        kmask = None
+        if attention_mask is not None:
+            # host-resident masks (collator output) are checked for padding without a device sync
+            if attention_mask.device.type == "cpu":
+                if not bool(attention_mask.all()):
+                    kmask = attention_mask.to(dev, dtype=torch.int32).contiguous()
+            else:
+                kmask = attention_mask.to(dtype=torch.int32).contiguous()
+        ids = input_ids.to(dev, dtype=torch.int64).contiguous()
+        B, S = ids.shape
+        if position_ids is None:
+            pos = torch.arange(S, device=dev, dtype=torch.int32).repeat(B)
+        else:
+            pos = position_ids.to(dev, dtype=torch.int32).reshape(-1).contiguous()
+        pix = None
+        if pixel_values is not None and pixel_values.numel() > 0:
+            pix = pixel_values.to(dev, dtype=torch.float32).contiguous()
+        need_grad = torch.is_grad_enabled() and self.train_flat.requires_grad
+        if need_grad:
+            return _LlavaFn.apply(self.train_flat, self, ids, kmask, pix, pos)
+        with torch.no_grad():
+            logits, _ = self._forward_impl(ids, kmask, pix, pos, save=False)
+        return logits
+
+    # CLIP tower + projector -> image features [n_img*np, dt]; returns tensors needed by projector backward
+    def _vision_forward(self, pix):
+        cfg, v, w = self.cfg, self.cfg.vision, self.w
+        dev = self.device
+        n = pix.shape[0]
+        npatch, T, dv = v.num_patches, v.num_patches + 1, v.hidden_size
+        col = torch.empty(n * npatch, v.patch_k_padded, device=dev, dtype=BF)
+        hip.im2col_patch(pix, col, v.patch_size)
+        patch = torch.empty(n * npatch, dv, device=dev, dtype=BF)
+        hip.gemm(hip.NT, col, w["vision.patch_embed.weight"], patch)
+        emb = torch.empty(n * T, dv, device=dev, dtype=BF)
+        hip.clip_embed(patch, w["vision.class_embedding"], w["vision.position_embedding"], emb, n, T, dv)
+        h = torch.empty_like(emb)
+        hip.layernorm_fwd(emb, w["vision.pre_ln.weight"], w["vision.pre_ln.bias"], h, v.layer_norm_eps)
+        y = torch.empty_like(h)
+        qkv = torch.empty(n * T, 3 * dv, device=dev, dtype=BF)
+        a = torch.empty_like(h)
+        z = torch.empty(n * T, v.intermediate_size, device=dev, dtype=BF)
+        scale = v.head_dim ** -0.5
+        for i in range(cfg.vision_layers_used):
+            p = f"vision.layers.{i}."
+            hip.layernorm_fwd(h, w[p + "ln1.weight"], w[p + "ln1.bias"], y, v.layer_norm_eps)
+            hip.gemm(hip.NT, y, w[p + "qkv.weight"], qkv, bias=w[p + "qkv.bias"])
+            hip.attn_fwd(qkv[:, :dv], qkv[:, dv:2 * dv], qkv[:, 2 * dv:], a, None, None, n, T, v.num_heads,
+                         v.head_dim, scale, False)
+            h2 = torch.empty_like(h)
+            hip.gemm(hip.NT, a, w[p + "out.weight"], h2, bias=w[p + "out.bias"], resid=h)
+            hip.layernorm_fwd(h2, w[p + "ln2.weight"], w[p + "ln2.bias"], y, v.layer_norm_eps)
+            hip.gemm(hip.NT, y, w[p + "fc1.weight"], z, bias=w[p + "fc1.bias"], act=hip.ACT_QUICK_GELU)
+            h = torch.empty_like(h2)
+            hip.gemm(hip.NT, z, w[p + "fc2.weight"], h, bias=w[p + "fc2.bias"], resid=h2)
+        feats = h.view(n, T, dv)[:, 1:].reshape(n * npatch, dv)  # drop CLS ("default" select strategy)
+        dt = cfg.text.hidden_size
+        p1 = torch.empty(n * npatch, dt, device=dev, dtype=BF)
+        hip.gemm(hip.NT, feats, w["projector.linear_1.weight"], p1, bias=w["projector.linear_1.bias"])
+        p1a = torch.empty_like(p1)
+        hip.gelu_fwd(p1, p1a)
+        img = torch.empty_like(p1)
+        hip.gemm(hip.NT, p1a, w["projector.linear_2.weight"], img, bias=w["projector.linear_2.bias"])
+        return img, (feats, p1, p1a)
+
+    def _forward_impl(self, ids, kmask, pix, pos, save: bool):
+        cfg, t, w = self.cfg, self.cfg.text, self.w
+        dev = self.device
+        B, S = ids.shape
+        M = B * S
+        dt, I, H, D = t.hidden_size, t.intermediate_size, t.num_heads, t.head_dim
+        assert S <= t.max_position
+        saved = {"B": B, "S": S, "ids": ids, "kmask": kmask, "pos": pos, "layers": []}
+        img = None
+        slot = None
+        if pix is not None:
+            img, vis_saved = self._vision_forward(pix)
+            slot = torch.empty(M, device=dev, dtype=torch.int32)
+            cnt = torch.empty(1, device=dev, dtype=torch.int32)
+            hip.image_slots(ids.view(-1), cfg.image_token_index, slot, cnt)
+            saved["vis"] = vis_saved
+        saved["slot"] = slot
+        h = torch.empty(M, dt, device=dev, dtype=BF)
+        hip.embed_fwd(ids.view(-1), slot, w["text.embed_tokens.weight"], img, h)
+        scale = D ** -0.5
+        y = torch.empty(M, dt, device=dev, dtype=BF)
+        self._last_capture = None
+        for i in range(t.num_layers):
+            p = f"text.layers.{i}."
+            rstd1 = torch.empty(M, device=dev, dtype=torch.float32)
+            hip.rmsnorm_fwd(h, w[p + "input_norm.weight"], y, rstd1, t.rms_norm_eps)
+            qkv = torch.empty(M, 3 * dt, device=dev, dtype=BF)
+            hip.gemm(hip.NT, y, w[p + "qkv.weight"], qkv)
+            hip.rope(qkv, pos, self._cos, self._sin, H, H, D, dt)
+            a = torch.empty(M, dt, device=dev, dtype=BF)
+            lse = torch.empty(B, H, S, device=dev, dtype=torch.float32) if save else None
+            hip.attn_fwd(qkv[:, :dt], qkv[:, dt:2 * dt], qkv[:, 2 * dt:], a, lse, kmask, B, S, H, D, scale, True)
+            h2 = torch.empty(M, dt, device=dev, dtype=BF)
+            hip.gemm(hip.NT, a, w[p + "o.weight"], h2, resid=h)
+            rstd2 = torch.empty(M, device=dev, dtype=torch.float32)
+            hip.rmsnorm_fwd(h2, w[p + "post_norm.weight"], y, rstd2, t.rms_norm_eps)
+            gu = torch.empty(M, 2 * I, device=dev, dtype=BF)
+            hip.gemm(hip.NT, y, w[p + "gate_up.weight"], gu)
+            act = torch.empty(M, I, device=dev, dtype=BF)
+            hip.swiglu_fwd(gu, act)
+            hn = torch.empty(M, dt, device=dev, dtype=BF)
+            hip.gemm(hip.NT, act, w[p + "down.weight"], hn, resid=h2)
+            if save:
+                saved["layers"].append((h, rstd1, qkv, a, lse, h2, rstd2, gu))
+            h = hn
+            if self.capture_layer is not None and i == self.capture_layer:
+                self._last_capture = h.view(B, S, dt)
+        rstdf = torch.empty(M, device=dev, dtype=torch.float32)
+        hip.rmsnorm_fwd(h, w["text.norm.weight"], y, rstdf, t.rms_norm_eps)
+        logits = torch.empty(M, t.vocab_size, device=dev, dtype=BF)
+        hip.gemm(hip.NT, y, w["lm_head.weight"], logits)
+        if save:
+            saved["final"] = (h, rstdf)
+        return logits.view(B, S, t.vocab_size), saved
+
+    # ---------------------------------------------------------------------------------------- backward
+    def _backward_impl(self, saved, dlogits):
+        cfg, t, w = self.cfg, self.cfg.text, self.w
+        dev = self.device
+        self.ensure_grad()
+        g = self.g
+        B, S = saved["B"], saved["S"]
+        M = B * S
+        dt, I, H, D, V = t.hidden_size, t.intermediate_size, t.num_heads, t.head_dim, t.vocab_size
+        scale = D ** -0.5
+        dlog = dlogits.reshape(M, V)
+        if not dlog.is_contiguous():
+            dlog = dlog.contiguous()
+        npart = hip.rmsnorm_bwd_nparts(M)
+        dw_part = torch.empty(npart * dt, device=dev, dtype=torch.float32)
+        y = torch.empty(M, dt, device=dev, dtype=BF)
+        hook = self.grad_ready_hook
+
+        h, rstdf = saved["final"]
+        hip.rmsnorm_fwd(h, w["text.norm.weight"], y, None, t.rms_norm_eps)
+        hip.gemm(hip.TN, dlog, y, g["lm_head.weight"], accumulate=True)
+        dy = torch.empty(M, dt, device=dev, dtype=BF)
+        hip.gemm(hip.NN, dlog, w["lm_head.weight"], dy)
+        dh = torch.empty(M, dt, device=dev, dtype=BF)
+        hip.rmsnorm_bwd(dy, h, w["text.norm.weight"], rstdf, None, dh, dw_part, g["text.norm.weight"], True)
+        if hook:
+            hook(self._off["text.norm.weight"][1], self.range_of("lm_head.weight")[1])
+        delta = torch.empty(B, H, S, device=dev, dtype=torch.float32)
+        layers = saved["layers"]
+        for i in reversed(range(t.num_layers)):
+            p = f"text.layers.{i}."
+            hin, rstd1, qkv, a, lse, h2, rstd2, gu = layers[i]
+            layers[i] = None
+            # MLP
+            act = torch.empty(M, I, device=dev, dtype=BF)
+            hip.swiglu_fwd(gu, act)
+            hip.gemm(hip.TN, dh, act, g[p + "down.weight"], accumulate=True)
+            dact = torch.empty(M, I, device=dev, dtype=BF)
+            hip.gemm(hip.NN, dh, w[p + "down.weight"], dact)
+            dgu = torch.empty(M, 2 * I, device=dev, dtype=BF)
+            hip.swiglu_bwd(gu, dact, dgu)
+            del act, dact, gu
+            hip.rmsnorm_fwd(h2, w[p + "post_norm.weight"], y, None, t.rms_norm_eps)
+            hip.gemm(hip.TN, dgu, y, g[p + "gate_up.weight"], accumulate=True)
+            hip.gemm(hip.NN, dgu, w[p + "gate_up.weight"], dy)
+            del dgu
+            dh2 = torch.empty(M, dt, device=dev, dtype=BF)
+            hip.rmsnorm_bwd(dy, h2, w[p + "post_norm.weight"], rstd2, dh, dh2, dw_part, g[p + "post_norm.weight"], True)
+            # attention
+            hip.gemm(hip.TN, dh2, a, g[p + "o.weight"], accumulate=True)
+            da = dh  # reuse the buffer of the (now consumed) upstream gradient
+            hip.gemm(hip.NN, dh2, w[p + "o.weight"], da)
+            dqkv = torch.empty(M, 3 * dt, device=dev, dtype=BF)
+            hip.attn_bwd(qkv[:, :dt], qkv[:, dt:2 * dt], qkv[:, 2 * dt:], a, lse, saved["kmask"], da, delta,
+                         dqkv[:, :dt], dqkv[:, dt:2 * dt], dqkv[:, 2 * dt:], B, S, H, D, scale, True)
+            hip.rope(dqkv, saved["pos"], self._cos, self._sin, H, H, D, dt, inverse=True)
+            del qkv, a
+            hip.rmsnorm_fwd(hin, w[p + "input_norm.weight"], y, None, t.rms_norm_eps)
+            hip.gemm(hip.TN, dqkv, y, g[p + "qkv.weight"], accumulate=True)
+            hip.gemm(hip.NN, dqkv, w[p + "qkv.weight"], dy)
+            del dqkv
+            dh = da  # overwrite: da is dead after attn_bwd
+            hip.rmsnorm_bwd(dy, hin, w[p + "input_norm.weight"], rstd1, dh2, dh, dw_part, g[p + "input_norm.weight"],
+                            True)
+            del dh2, hin, h2
+            if hook:
+                hook(*self.layer_grad_range(i))
+        # embeddings / projector
+        slot = saved["slot"]
+        dimg = None
+        if "vis" in saved:
+            feats, p1, p1a = saved["vis"]
+            dimg = torch.zeros(p1.shape[0], dt, device=dev, dtype=BF)
+        if self._embed_scratch is None:
+            self._embed_scratch = torch.zeros(V, dt, device=dev, dtype=torch.float32)
+            self._embed_flag = torch.zeros(V, device=dev, dtype=torch.int32)
+        hip.embed_bwd(saved["ids"].view(-1), slot, dh, dimg, self._embed_scratch, self._embed_flag,
+                      g["text.embed_tokens.weight"], V)
+        if dimg is not None:
+            n = dimg.shape[0]
+            cpart = torch.empty(hip.colsum_nparts(n) * dt, device=dev, dtype=torch.float32)
+            hip.gemm(hip.TN, dimg, p1a, g["projector.linear_2.weight"], accumulate=True)
+            hip.colsum(dimg, cpart, g["projector.linear_2.bias"], True)
+            dp1a = torch.empty_like(p1)
+            hip.gemm(hip.NN, dimg, w["projector.linear_2.weight"], dp1a)
+            dp1 = torch.empty_like(p1)
+            hip.gelu_bwd(p1, dp1a, dp1)
+            hip.gemm(hip.TN, dp1, feats, g["projector.linear_1.weight"], accumulate=True)
+            hip.colsum(dp1, cpart, g["projector.linear_1.bias"], True)
+        if hook:
+            hook(0, self.range_of("text.embed_tokens.weight")[1])
+
+
+class _LlavaFn(torch.autograd.Function):
+    """Autograd edge: logits = f(train_flat).  backward() runs the explicit reverse sweep, ACCUMULATES straight
+    into the model's flat gradient buffer (train_flat.grad) and returns no tensor for it."""
+
+    @staticmethod
+    def forward(ctx, train_flat, model: LlavaHIP, ids, kmask, pix, pos):
+        logits, saved = model._forward_impl(ids, kmask, pix, pos, save=True)
+        ctx.model = model
+        ctx.saved = saved
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        model, saved = ctx.model, ctx.saved
+        ctx.saved = None
+        model._backward_impl(saved, dlogits)
+        return None, None, None, None, None, None

@@ -1,0 +1,240 @@
+"""Drop-in counterpart of the reference's MMTrainerForgetting (mm/trainer.py:112-492).
+
+Same constructor kwargs (`forget_loss, teacher_model, loss_beta, l1_lambda, l0_lambda, l_norm_from, loss_args`,
+mm/trainer.py:113-123; call site mm/forget.py:171-187), same `compute_loss(model, inputs, return_outputs=False,
+*args, **kwargs)` signature (mm/trainer.py:168), same nested-dict `inputs` (mm/dataset.py:283-288), same
+exceptions (ValueError for unknown losses / bad l_norm_from / L1 without teacher / LoRA with "zero").
+`model(**split)` must return an object with `.loss` and `.logits` (our LlavaHIP, or anything HF-shaped).
+
+Differences on purpose: both "KL" and "kl" need/accept a teacher; `model.device = ...` is not
+assigned; `return_outputs=True` returns the last student output for every branch; the dead forwards of the dpo
+branch run only if loss_args["dpo_dead_compute"] is set (they never influence the loss, mm/trainer.py:394-396).
+
+MI355X addition — paired forget/retain fusion: when both splits have the same sequence length, the branches that
+only need CE terms (grad_diff_forget_ce_retain_ce, eco_ft, idk) run ONE forward over the concatenated batch and get
+the per-split means from the segmented CE kernel.  Rows never interact, so each split's loss and gradient are
+the same as with two separate forwards; it doubles the GEMM M dimension and halves launches.
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, Optional
+
+import torch
+
+from . import trainer_utils as tu
+from .llava import segment_ce_losses
+
+_SPLIT_KEYS = ("input_ids", "attention_mask", "pixel_values", "labels")
+
+
+class MMTrainerForgetting:
+    def __init__(self, *args, **kwargs):
+        self.loss_type = kwargs.pop("forget_loss").lower()
+        self.teacher_model = kwargs.pop("teacher_model", None)
+        self.loss_beta = kwargs.pop("loss_beta", 1.0)
+        self.l1_lambda = kwargs.pop("l1_lambda", 0.0)
+        self.l0_lambda = kwargs.pop("l0_lambda", 0.0)
+        self.l_norm_from = kwargs.pop("l_norm_from", "zero")
+        self.loss_args = kwargs.pop("loss_args", {}) or {}
+        if self.l1_lambda and self.l1_lambda != 0 and self.l_norm_from not in ("zero", "init"):
+            raise ValueError(f"Invalid l_norm_from {self.l_norm_from}, should be 'zero' or 'init'")
+        # HF-Trainer style positional/keyword leftovers (model, args, train_dataset, data_collator, tokenizer ...)
+        self.model = kwargs.pop("model", args[0] if args else None)
+        self.args = kwargs.pop("args", None)
+        self.train_dataset = kwargs.pop("train_dataset", None)
+        self.data_collator = kwargs.pop("data_collator", None)
+        self.tokenizer = kwargs.pop("tokenizer", None)
+        self.fuse_pairs = bool(self.loss_args.get("fuse_pairs", True))
+        self.is_deepspeed_enabled = False
+        if tu.loss_needs_teacher(self.loss_type) and self.teacher_model is None:
+            raise ValueError(f"forget_loss={self.loss_type} evaluates a frozen teacher: pass teacher_model")
+        if self.teacher_model is not None and hasattr(self.teacher_model, "parameters"):
+            for p in self.teacher_model.parameters():  # mm/trainer.py:157-160
+                p.requires_grad = False
+
+    @staticmethod
+    def to_device(device, inputs):  # mm/trainer.py:164-166
+        return {k: v.to(device) for k, v in inputs.items()}
+
+    # ------------------------------------------------------------------------------------------------
+    def _teacher(self, split):
+        with torch.no_grad():
+            return self.teacher_model(**split)
+
+    @staticmethod
+    def _can_fuse(a, b):
+        return (a is not None and b is not None and a["input_ids"].shape == b["input_ids"].shape
+                and a["pixel_values"].shape[1:] == b["pixel_values"].shape[1:])
+
+    def _paired_ce(self, model, a, b):
+        """One forward over cat(a, b); returns (ce_a, ce_b, outputs)."""
+        cat = {k: torch.cat([a[k], b[k]], dim=0) for k in _SPLIT_KEYS if k in a and k != "labels"}
+        out = model(**cat)
+        labels = torch.cat([a["labels"], b["labels"]], dim=0).to(out.logits.device)
+        ce = segment_ce_losses(out.logits, labels, 2)
+        return ce[0], ce[1], out
+
+    def compute_loss(self, model, inputs, return_outputs=False, *args, **kwargs):
+        dev = next(model.parameters()).device
+        retain_inputs = self.to_device(dev, inputs["retain"]) if "retain" in inputs else None
+        idk_inputs = self.to_device(dev, inputs["idk"]) if "idk" in inputs else None
+        forget_inputs = self.to_device(dev, inputs["forget"]) if "forget" in inputs else None
+        random_inputs = self.to_device(dev, inputs["random"]) if "random" in inputs else None
+        lt, beta = self.loss_type, self.loss_beta
+        outputs = None
+
+        if lt == "retain_ft":
+            outputs = model(**retain_inputs)
+            loss = outputs.loss
+
+        elif lt == "grad_ascent":
+            outputs = model(**forget_inputs)
+            loss = -1 * outputs.loss
+
+        elif lt.startswith("grad_diff"):
+            if "forget_ce" in lt and "retain_ce" in lt and self.fuse_pairs and self._can_fuse(forget_inputs, retain_inputs):
+                forget_loss, retain_loss, outputs = self._paired_ce(model, forget_inputs, retain_inputs)
+            else:
+                forget_outputs = model(**forget_inputs)
+                retain_outputs = model(**retain_inputs)
+                outputs = retain_outputs
+                if "forget_ce" in lt:
+                    forget_loss = forget_outputs.loss
+                elif "forget_entropy" in lt:
+                    forget_loss = tu.entropy_term(forget_outputs.logits)
+                elif "forget_kl" in lt:
+                    oracle = self._teacher(forget_inputs)
+                    forget_loss = tu.kl_div_batchmean(forget_outputs.logits, oracle.logits, student_is_input=True)
+                else:
+                    raise ValueError(f"Invalid loss type on forget {self.loss_type}")
+                if "retain_ce" in lt:
+                    retain_loss = retain_outputs.loss
+                elif "retain_kl" in lt:
+                    oracle = self._teacher(retain_inputs)
+                    retain_loss = tu.kl_div_batchmean(retain_outputs.logits, oracle.logits, student_is_input=True)
+                else:
+                    raise ValueError(f"Invalid loss type on retain {self.loss_type}")
+            loss = -1 * beta * forget_loss + retain_loss
+
+        elif lt == "scrub":
+            forget_outputs = model(**forget_inputs)
+            oracle_f = self._teacher(forget_inputs)
+            kl_forget = tu.kl_div_batchmean(oracle_f.logits, forget_outputs.logits, student_is_input=False)
+            retain_outputs = model(**retain_inputs)
+            oracle_r = self._teacher(retain_inputs)
+            kl_retain = tu.kl_div_batchmean(oracle_r.logits, retain_outputs.logits, student_is_input=False)
+            loss = -1 * beta * kl_forget + kl_retain + retain_outputs.loss
+            outputs = retain_outputs
+
+        elif lt == "kl":
+            forget_outputs = model(**forget_inputs)
+            forget_loss = -1 * forget_outputs.loss
+            oracle_r = self._teacher(retain_inputs)
+            retain_outputs = model(**retain_inputs)
+            retain_loss = tu.kl_div_batchmean(retain_outputs.logits, oracle_r.logits, student_is_input=True)
+            loss = forget_loss + retain_loss
+            outputs = retain_outputs
+
+        elif lt == "llmu":
+            forget_loss = -1 * model(**forget_inputs).loss
+            random_loss = model(**idk_inputs).loss
+            retain_outputs = model(**retain_inputs)
+            oracle_r = self._teacher(retain_inputs)
+            retain_loss = tu.kl_div_batchmean(oracle_r.logits, retain_outputs.logits, student_is_input=False)
+            loss = forget_loss + retain_loss + random_loss
+            outputs = retain_outputs
+
+        elif lt == "npo":
+            outputs = model(**forget_inputs)
+            oracle_f = self._teacher(forget_inputs)
+            loss = tu.npo_loss(outputs.logits, oracle_f.logits, beta)
+
+        elif lt == "idk":
+            if self.fuse_pairs and self._can_fuse(retain_inputs, idk_inputs):
+                a, b, outputs = self._paired_ce(model, retain_inputs, idk_inputs)
+                loss = a + b
+            else:
+                retain_outputs = model(**retain_inputs)
+                outputs = model(**idk_inputs)
+                loss = retain_outputs.loss + outputs.loss
+
+        elif lt == "eco_ft":
+            if self.fuse_pairs and self._can_fuse(forget_inputs, retain_inputs):
+                a, b, outputs = self._paired_ce(model, forget_inputs, retain_inputs)
+                loss = beta * a + b
+            else:
+                forget_outputs = model(**forget_inputs)
+                outputs = model(**retain_inputs)
+                loss = beta * forget_outputs.loss + outputs.loss
+
+        elif lt == "dpo":
+            # mm/trainer.py:364-398: the log-sigmoid DPO value is overwritten twice; what is returned (and
+            # differentiated) is mean_b sum_t CE on the idk split.  The three other forwards are dead compute.
+            idk_outputs = model(**idk_inputs)
+            if self.loss_args.get("dpo_dead_compute", False):
+                outputs = model(**forget_inputs)
+                self._teacher(idk_inputs)
+                self._teacher(forget_inputs)
+            else:
+                outputs = idk_outputs
+            image_token_index = model.config.image_token_index
+            idk_logits = tu.remove_image_tokens(idk_inputs["input_ids"], idk_outputs.logits, image_token_index)
+            idk_loss_current = -1 * tu.get_batch_loss(idk_logits, idk_inputs["labels"])
+            loss = -idk_loss_current.mean()
+
+        elif lt == "sku":
+            bad_loss = model(**forget_inputs).loss
+            # [B, K, ...] -> K batches; the reference transposes in place (mm/trainer.py:420-421); we do not mutate
+            K = random_inputs["input_ids"].shape[1]
+            random_loss = 0.0
+            for i in range(K):
+                random_loss = random_loss + model(**{k: v[:, i] for k, v in random_inputs.items()}).loss
+            oracle_r = self._teacher(retain_inputs)
+            outputs = model(**retain_inputs)
+            normal_loss = -1 * tu.kl_div_batchmean(outputs.logits, oracle_r.logits, student_is_input=True)
+            loss = (self.loss_args["bad_weight"] * bad_loss + self.loss_args["random_weight"] * random_loss
+                    + self.loss_args["normal_weight"] * normal_loss)
+
+        elif lt == "rmu":
+            raise NotImplementedError("rmu (mm/trainer.py:302-326) is outside BASELINE's loss surface; SURVEY §8f row 4")
+
+        else:
+            raise ValueError(f"Invalid loss type {self.loss_type}")
+
+        loss = loss + self._l_norm_regulariser(model)
+        return (loss, outputs) if return_outputs else loss
+
+    # mm/trainer.py:451-481
+    def _l_norm_regulariser(self, model):
+        l1, l0 = self.l1_lambda, self.l0_lambda
+        if not ((l1 is not None and l1 != 0) or (l0 is not None and l0 != 0)):
+            return 0.0
+        params = []
+        lora = tu.has_lora_adapter(model)
+        if self.l_norm_from == "init":
+            if lora:
+                params = [p.view(-1) for p in model.parameters() if p.requires_grad]
+            else:
+                if self.teacher_model is None:
+                    raise ValueError("Teacher model is required for L1\\L0 regularization during training without LORA!")
+                for p, tp in zip(model.parameters(), self.teacher_model.parameters()):
+                    assert p.shape == tp.shape
+                    if p.requires_grad:
+                        params.append((p - tp.to(p.device)).view(-1))
+        elif self.l_norm_from == "zero":
+            if lora:
+                raise ValueError("L1\\L0 regularization is not supported for LORA!")
+            params = [p.view(-1) for p in model.parameters() if p.requires_grad]
+        reg = 0.0
+        cat = torch.cat(params).float()
+        if l1 is not None and l1 != 0:
+            reg = reg + l1 * torch.norm(cat, p=1)
+        if l0 is not None and l0 != 0:
+            reg = reg + l0 * torch.norm(cat, p=0)
+        return reg
+
+    def prediction_step(self, model, inputs, prediction_loss_only: bool, ignore_keys=None):  # mm/trainer.py:485-492
+        input_ids, labels, attention_mask = inputs
+        with torch.no_grad():
+            outputs = model(input_ids=input_ids, labels=labels, attention_mask=attention_mask)
+        return (outputs.loss, outputs.logits, labels)

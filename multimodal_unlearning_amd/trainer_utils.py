@@ -1,0 +1,75 @@
+"""Host-side mirror of /root/reference/mm/trainer_utils.py (same names, argument meaning and results), with the
+[N,V] arithmetic routed to the HIP loss kernels (csrc/loss.hip) instead of ATen."""
+from __future__ import annotations
+
+import torch
+
+from . import hip
+from .llava import row_loss_sum, sequence_ce_sums
+
+LOSSES_WITH_TEACHER = ("DPO", "SCRUB", "RMU", "LLMU", "SKU", "NPO")  # mm/trainer_utils.py:5
+
+
+def loss_needs_teacher_reference(loss_type: str) -> bool:
+    """Bit-for-bit behaviour of mm/trainer_utils.py:8-9 — case-sensitive "KL" test (a latent defect of the
+    reference: the trainer lower-cases loss_type)."""
+    return "KL" in loss_type or loss_type.upper() in LOSSES_WITH_TEACHER
+
+
+def loss_needs_teacher(loss_type: str) -> bool:
+    """What the dispatcher actually needs: a teacher iff the branch evaluates one (either case accepted)."""
+    lt = loss_type.lower()
+    return "kl" in lt or lt.upper() in LOSSES_WITH_TEACHER
+
+
+def has_lora_adapter(model) -> bool:  # mm/trainer_utils.py:12-13
+    return any(True for name, _ in model.named_parameters() if "lora" in name)
+
+
+def kl_div_batchmean(input_logits, target_logits, student_is_input: bool):
+    """F.kl_div(logits2probs(input), logits2probs(target), reduction="batchmean", log_target=True) as the reference
+    calls it (mm/trainer.py:203-208 etc.): divides by ALL B*S rows.  Exactly one side is the student (the side
+    that carries gradient); `student_is_input` says which."""
+    V = input_logits.shape[-1]
+    n_rows = input_logits.numel() // V
+    if student_is_input:
+        s = row_loss_sum(input_logits, target_logits, hip.KL_STUDENT_INPUT)
+    else:
+        s = row_loss_sum(target_logits, input_logits, hip.KL_TEACHER_INPUT)
+    return s / n_rows
+
+
+def npo_loss(student_logits, teacher_logits, beta: float):
+    """(2/beta) * mean_{n,v} log(1 + (p/(p_T + 1e-8))^beta)   (mm/trainer.py:348-353)."""
+    n = student_logits.numel()
+    return (2.0 / beta) * row_loss_sum(student_logits, teacher_logits, hip.NPO, beta) / n
+
+
+def entropy_term(student_logits):
+    """torch.sum(p * log p) over every row and vocab entry (mm/trainer.py:195-196)."""
+    return row_loss_sum(student_logits, None, hip.ENTROPY)
+
+
+def get_batch_loss(output, labels):
+    """mm/trainer_utils.py:73-81: per-sequence SUM of the shifted CE -> [B]."""
+    return sequence_ce_sums(output, labels.to(output.device))
+
+
+def remove_image_tokens(input_ids, logits, image_token_id):
+    """mm/trainer_utils.py:48-70.  With pre-expanded <image> ids (transformers >= 4.47 processors, and every batch
+    this repo builds) logits and ids have the same length and the function is the identity; the general slicing
+    is kept for un-expanded ids."""
+    B, T = input_ids.shape
+    if logits.shape[1] == T:
+        return logits
+    search = (input_ids == image_token_id).nonzero(as_tuple=True)
+    has = search[0].tolist()
+    idx = search[1].tolist()
+    res = []
+    for i in range(B):
+        if i not in has:
+            res.append(logits[i, -T:, :])
+            continue
+        start = idx[has.index(i)]
+        res.append(torch.cat([logits[i, :start, :], logits[i, -(T - start):, :]]))
+    return torch.stack(res)

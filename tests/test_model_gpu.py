@@ -1,0 +1,167 @@
+"""GPU parity of the HIP LLaVA + compute_loss path against (a) the committed golden vectors produced by the
+reference's own compute_loss / transformers (fp32) and (b) the oracle run live on the same inputs.
+
+Tolerances (bf16 activations and weights vs an fp32 reference of the same bf16-rounded weights):
+  logits   relative L2 error < 1e-2  (measured ~3e-3)
+  loss     |d| < 1e-3 * max(1, |loss|)  -- BASELINE.json north_star "within 1e-3 bf16"; the entropy / dpo
+           branches are SUMS over thousands of terms and use the same RELATIVE bound
+  grads    total-norm relative error < 2e-2
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from multimodal_unlearning_amd.config import ForgetConfig, tiny_test_config  # noqa: E402
+from multimodal_unlearning_amd.params import init_params  # noqa: E402
+from multimodal_unlearning_amd.synthetic import make_forget_batch, teacher_params_from  # noqa: E402
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+KEYS = ("input_ids", "attention_mask", "pixel_values", "labels")
+GRAD_KEYS = ["lm_head.weight", "text.embed_tokens.weight", "text.layers.0.qkv.weight", "text.layers.1.down.weight",
+             "text.norm.weight", "projector.linear_1.weight", "projector.linear_2.bias"]
+
+
+@pytest.fixture(scope="module")
+def models(dev):
+    from multimodal_unlearning_amd.llava import LlavaHIP
+
+    cfg = tiny_test_config()
+    P = init_params(cfg, seed=0)
+    student = LlavaHIP(cfg, P, device=dev)
+    teacher = LlavaHIP(cfg, teacher_params_from(P, seed=7), device=dev, trainable=False)
+    return cfg, P, student, teacher
+
+
+def _relerr(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-12)).item()
+
+
+@pytest.mark.parametrize("tag", ["forget", "padded"])
+def test_forward_backward_vs_hf_golden_and_oracle(models, tag):
+    from oracle.llava_ref import llava_forward
+
+    cfg, P, student, _ = models
+    g = np.load(os.path.join(G, "llava_tiny_hf.npz"))
+    sp = {k: torch.from_numpy(g[f"{tag}.in.{k}"]) for k in KEYS}
+    student.ensure_grad().zero_()
+    out = student(**sp)
+    out.loss.backward()
+    torch.cuda.synchronize()
+    valid = sp["attention_mask"].bool()
+    ref_logits = torch.from_numpy(g[f"{tag}.logits"])
+    e = _relerr(out.logits.cpu()[valid], ref_logits[valid])
+    assert e < 1e-2, e
+    ref_loss = float(g[f"{tag}.loss"])
+    assert abs(out.loss.item() - ref_loss) < 1e-3 * max(1.0, abs(ref_loss)), (out.loss.item(), ref_loss)
+    for k in GRAD_KEYS:
+        gn = student.g[k].float().norm().item()
+        rn = float(g[f"{tag}.gradnorm.{k}"])
+        assert abs(gn - rn) < 2e-2 * max(rn, 1e-3), (k, gn, rn)
+    assert _relerr(student.g["text.norm.weight"], torch.from_numpy(g[f"{tag}.grad.text.norm.weight"])) < 2e-2
+    # live oracle in bf16 (the HF CPU bf16 path): the HIP path must be at least as close to fp32 as it is
+    Pb = {k: v.clone() for k, v in P.items()}
+    ob = llava_forward(cfg, Pb, **sp, dtype=torch.bfloat16)
+    e_bf16_oracle = _relerr(ob["logits"].float()[valid], ref_logits[valid])
+    assert e < 2.0 * e_bf16_oracle + 1e-3, (e, e_bf16_oracle)
+    # full-tensor gradient check against the fp32 oracle's autograd
+    Pf = {k: v.clone().requires_grad_(not k.startswith("vision.")) for k, v in P.items()}
+    of = llava_forward(cfg, Pf, **sp)
+    of["loss"].backward()
+    for k in GRAD_KEYS + ["text.layers.0.gate_up.weight", "text.layers.1.o.weight", "text.layers.0.input_norm.weight",
+                          "projector.linear_1.bias", "projector.linear_2.weight"]:
+        assert _relerr(student.g[k], Pf[k].grad) < 3e-2, (k, _relerr(student.g[k], Pf[k].grad))
+
+
+LOSS_TYPES = ["retain_ft", "grad_ascent", "grad_diff_forget_ce_retain_ce", "grad_diff_forget_entropy_retain_ce",
+              "grad_diff_forget_kl_retain_ce", "grad_diff_forget_ce_retain_kl", "KL", "scrub", "npo", "idk", "eco_ft",
+              "dpo", "llmu"]
+
+
+@pytest.mark.parametrize("lt", LOSS_TYPES)
+def test_compute_loss_vs_reference_golden(models, lt):
+    from multimodal_unlearning_amd.trainer import MMTrainerForgetting
+
+    cfg, P, student, teacher = models
+    g = np.load(os.path.join(G, "compute_loss_tiny.npz"))
+    inputs = {s: {k: torch.from_numpy(g[f"in.{s}.{k}"]) for k in KEYS} for s in ("forget", "retain", "idk")}
+    tr = MMTrainerForgetting(model=student, forget_loss=lt, teacher_model=teacher, loss_beta=0.7, l1_lambda=0.0,
+                             l0_lambda=0.0, l_norm_from="zero", loss_args={})
+    student.ensure_grad().zero_()
+    loss = tr.compute_loss(student, inputs)
+    loss.backward()
+    torch.cuda.synchronize()
+    ref = float(g[f"{lt}.loss"])
+    assert abs(loss.item() - ref) < 1e-3 * max(1.0, abs(ref)), (lt, loss.item(), ref)
+    tot = student.ensure_grad().float().norm().item()
+    rt = float(g[f"{lt}.gradnorm.total"])
+    assert abs(tot - rt) < 2e-2 * rt, (lt, tot, rt)
+    for k in GRAD_KEYS:
+        gn = student.g[k].float().norm().item()
+        rn = float(g[f"{lt}.gradnorm.{k}"])
+        assert abs(gn - rn) < 3e-2 * max(rn, 1e-2 * rt), (lt, k, gn, rn)
+
+
+def test_l1_regulariser_and_errors(models):
+    from multimodal_unlearning_amd.trainer import MMTrainerForgetting
+
+    cfg, P, student, teacher = models
+    g = np.load(os.path.join(G, "compute_loss_tiny.npz"))
+    inputs = {s: {k: torch.from_numpy(g[f"in.{s}.{k}"]) for k in KEYS} for s in ("forget", "retain", "idk")}
+    tr = MMTrainerForgetting(model=student, forget_loss="grad_ascent", teacher_model=teacher, loss_beta=0.7,
+                             l1_lambda=1e-4, l0_lambda=0.0, l_norm_from="init", loss_args={})
+    loss = tr.compute_loss(student, inputs)
+    ref = float(g["grad_ascent+l1_init.loss"])
+    assert abs(loss.item() - ref) < 2e-3 * max(1.0, abs(ref)), (loss.item(), ref)
+    with pytest.raises(ValueError):
+        MMTrainerForgetting(model=student, forget_loss="grad_ascent", teacher_model=None, loss_beta=1.0,
+                            l1_lambda=0.1, l0_lambda=0.0, l_norm_from="bogus")
+    with pytest.raises(ValueError):
+        MMTrainerForgetting(model=student, forget_loss="not_a_loss", teacher_model=None, loss_beta=1.0, l1_lambda=0,
+                            l0_lambda=0, l_norm_from="zero").compute_loss(student, inputs)
+    with pytest.raises(ValueError):
+        MMTrainerForgetting(model=student, forget_loss="grad_diff_forget_x_retain_ce", teacher_model=None, loss_beta=1.0,
+                            l1_lambda=0, l0_lambda=0, l_norm_from="zero").compute_loss(student, inputs)
+    with pytest.raises(ValueError):  # L1 from init without a teacher
+        MMTrainerForgetting(model=student, forget_loss="grad_ascent", teacher_model=None, loss_beta=1.0, l1_lambda=0.1,
+                            l0_lambda=0, l_norm_from="init").compute_loss(student, inputs)
+
+
+def test_paired_fusion_is_equivalent(models):
+    from multimodal_unlearning_amd.trainer import MMTrainerForgetting
+
+    cfg, P, student, _ = models
+    inputs = make_forget_batch(cfg, 3, 40, seed=5, n_question=7)
+    res = {}
+    for fuse in (True, False):
+        tr = MMTrainerForgetting(model=student, forget_loss="grad_diff_forget_ce_retain_ce", teacher_model=None,
+                                 loss_beta=1.3, l1_lambda=0, l0_lambda=0, l_norm_from="zero",
+                                 loss_args={"fuse_pairs": fuse})
+        student.ensure_grad().zero_()
+        loss = tr.compute_loss(student, inputs)
+        loss.backward()
+        res[fuse] = (loss.item(), student.ensure_grad().clone())
+    # forward rows are independent -> identical logits and CE; wgrads differ only by bf16 accumulation order
+    assert abs(res[True][0] - res[False][0]) < 1e-5 * max(1, abs(res[False][0]))
+    assert _relerr(res[True][1], res[False][1]) < 1e-2
+
+
+def test_engine_steps_reduce_retain_loss(models, dev):
+    from multimodal_unlearning_amd.engine import ForgetEngine
+    from multimodal_unlearning_amd.llava import LlavaHIP
+    from multimodal_unlearning_amd.trainer import MMTrainerForgetting
+
+    cfg, P, _, _ = models
+    model = LlavaHIP(cfg, P, device=dev)
+    tr = MMTrainerForgetting(model=model, forget_loss="retain_ft", teacher_model=None, loss_beta=1.0, l1_lambda=0,
+                             l0_lambda=0, l_norm_from="zero")
+    eng = ForgetEngine(model, tr, ForgetConfig(lr=2e-3, weight_decay=0.0), total_steps=50, warmup_steps=2)
+    mbs = [make_forget_batch(cfg, 2, 32, seed=s, n_question=5) for s in (1, 2)]
+    losses = [eng.step(mbs, sync_loss=True).loss for _ in range(8)]
+    assert all(np.isfinite(losses)), losses
+    assert losses[-1] < losses[0] - 0.5, losses
+    assert model.ensure_grad().abs().max().item() == 0  # fused zeroing after the optimiser step
