@@ -1,0 +1,261 @@
+#!/usr/bin/env python3
+"""Forget-step throughput on MI355X: samples/s (forget+retain image+QA pairs) of the LLaVA-1.5-7B
+grad_diff_forget_ce_retain_ce step (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...; one rank per GPU, RCCL)
+
+A "step" = one optimiser step = GA micro-batches x [compute_loss forward + backward over B pairs] + bucketed
+gradient all-reduce (N>1) + global-norm clip + AdamW + grad zeroing.  Random-init weights of the named
+architecture, synthetic batches resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+
+roofline: the dominant kernel is the bf16 MFMA GEMM (>= 95 % of the step's FLOPs).  On the LAST timed step every
+GEMM launch is bracketed by HIP events on the launch stream; achieved = sum(2*M*N*K) / sum(duration) over those
+launches, peak = 2.5 PFLOP/s dense bf16 (MI355X_MICROARCH.md).  cpu_baseline: the oracle (oracle/llava_ref.py,
+bf16 CPU path) timed on the host cores of this box on a bounded full-width sample, extrapolated linearly in depth.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_BF16 = 2.5e15  # dense bf16 MFMA FLOP/s per MI355X
+
+
+def flops_per_sample(cfg, S, paired=True):
+    """Algorithmic FLOPs of one grad_diff full-FT sample (forget + retain sequence), vision tower frozen:
+    matmul = 2mnk, causal attention at half the dense S^2."""
+    t, v = cfg.text, cfg.vision
+    d, I, L, V = t.hidden_size, t.intermediate_size, t.num_layers, t.vocab_size
+    lin = 2 * S * (4 * d * d + 3 * d * I) * L
+    attn = 2 * 2 * S * S * d * L / 2
+    head = 2 * S * d * V
+    dec = lin + attn + head
+    T = v.num_patches + 1
+    dv, iv = v.hidden_size, v.intermediate_size
+    clip = cfg.vision_layers_used * (2 * T * (4 * dv * dv + 2 * dv * iv) + 2 * 2 * T * T * dv) + 2 * v.num_patches * v.patch_k * dv
+    proj = 2 * v.num_patches * (dv * d + d * d)
+    fwd = dec + clip + proj
+    fb = fwd + 2 * (dec + proj)
+    return (2 if paired else 1) * fb
+
+
+class GemmTimer:
+    """Brackets every hip.gemm launch with HIP events on the current (launch) stream."""
+
+    def __init__(self, hipmod):
+        self.hip = hipmod
+        self.orig = hipmod.gemm
+        self.records = []
+
+    def __enter__(self):
+        def timed(layout, A, B, out, **kw):
+            s = torch.cuda.current_stream()
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record(s)
+            r = self.orig(layout, A, B, out, **kw)
+            e1.record(s)
+            if layout == self.hip.NT:
+                m, k = A.shape
+                n = B.shape[0]
+            elif layout == self.hip.NN:
+                m, k = A.shape
+                n = B.shape[1]
+            else:
+                k, m = A.shape
+                n = B.shape[1]
+            self.records.append((layout, m, n, k, e0, e1))
+            return r
+
+        self.hip.gemm = timed
+        return self
+
+    def __exit__(self, *a):
+        self.hip.gemm = self.orig
+
+    def summary(self):
+        torch.cuda.synchronize()
+        tot_f = tot_t = 0.0
+        by = {}
+        for layout, m, n, k, e0, e1 in self.records:
+            ms = e0.elapsed_time(e1)
+            f = 2.0 * m * n * k
+            tot_f += f
+            tot_t += ms * 1e-3
+            key = ("NT", "NN", "TN")[layout]
+            b = by.setdefault(key, [0, 0.0, 0.0])
+            b[0] += 1
+            b[1] += f
+            b[2] += ms * 1e-3
+        return tot_f, tot_t, len(self.records), {k: {"launches": v[0], "tflops": round(v[1] / v[2] / 1e12, 1),
+                                                     "avg_us": round(v[2] / v[0] * 1e6, 1)} for k, v in by.items()}
+
+
+def cpu_baseline(cfg, S, budget_layers=1, clip_layers=2):
+    """Oracle (bf16 CPU restatement of the reference path) on the host cores: full-width model cut to
+    `budget_layers` decoder layers and `clip_layers` CLIP layers, one forget+retain pair at B=1, fwd+bwd of
+    grad_diff; the per-layer terms are extrapolated linearly to the full depth."""
+    import copy
+
+    from multimodal_unlearning_amd.params import param_specs
+    from multimodal_unlearning_amd.synthetic import make_forget_batch
+    from oracle.forget_losses_ref import compute_loss_ref
+    from oracle.llava_ref import llava_forward
+
+    torch.set_num_threads(os.cpu_count() or 1)
+    cores = torch.get_num_threads()
+
+    def build(nl, ncl):
+        c = copy.deepcopy(cfg)
+        c.text.num_layers = nl
+        c.vision.num_layers = ncl + 1  # vision_layers_used = num_layers - 1
+        g = torch.Generator().manual_seed(0)
+        P = {}
+        for name, shape in param_specs(c).items():
+            if name.endswith(("norm.weight", "ln1.weight", "ln2.weight", "pre_ln.weight")):
+                t = torch.ones(shape, dtype=torch.bfloat16)
+            else:
+                t = (torch.randn(shape, generator=g) * 0.02).to(torch.bfloat16)
+            P[name] = t.requires_grad_(not name.startswith("vision."))
+        return c, P
+
+    def run(nl, ncl):
+        c, P = build(nl, ncl)
+        batch = make_forget_batch(c, 1, S, seed=1, n_question=S - 1 - c.vision.num_patches - 256)
+        t0 = time.perf_counter()
+        loss = compute_loss_ref("grad_diff_forget_ce_retain_ce",
+                                lambda x: llava_forward(c, P, **x, dtype=torch.bfloat16), None, batch, 1.0)
+        loss.backward()
+        return time.perf_counter() - t0
+
+    run(0, 1)  # warm-up (allocator, thread pool)
+    t_base = run(0, clip_layers)             # embeddings + CLIP(clip_layers) + projector + lm_head + loss
+    t_full = run(budget_layers, clip_layers)  # + budget_layers decoder layers
+    t_clip1 = run(0, 1)
+    per_dec = max(1e-6, (t_full - t_base) / budget_layers)
+    per_clip = max(0.0, (t_base - t_clip1) / max(1, clip_layers - 1))
+    est = t_base + per_dec * cfg.text.num_layers + per_clip * (cfg.vision_layers_used - clip_layers)
+    return {"value": round(1.0 / est, 6), "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": (f"oracle/llava_ref.py bf16 on host cores: full-width {budget_layers}/{cfg.text.num_layers} decoder "
+                       f"layers + {clip_layers}/{cfg.vision_layers_used} CLIP layers + projector + lm_head + CE, one "
+                       f"forget+retain pair (B=1, S={S}) fwd+bwd, measured {t_full:.1f}s, per-layer terms extrapolated "
+                       f"linearly to full depth ({est:.0f}s per sample)")}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--micro-batch", type=int, default=4, help="forget+retain pairs per GPU per micro-batch")
+    ap.add_argument("--grad-accum", type=int, default=4, help="reference default (config/mm/forget.yaml:15)")
+    ap.add_argument("--model", default="7b", choices=["7b", "13b", "tiny"])
+    ap.add_argument("--loss", default="grad_diff_forget_ce_retain_ce")
+    ap.add_argument("--layers", type=int, default=0, help="debug: override decoder depth (invalidates the metric)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fuse", action="store_true")
+    args = ap.parse_args()
+
+    from multimodal_unlearning_amd import hip
+    from multimodal_unlearning_amd.config import ForgetConfig, llava_1_5_7b, llava_1_5_13b, tiny_test_config
+    from multimodal_unlearning_amd.engine import ForgetEngine, init_distributed
+    from multimodal_unlearning_amd.llava import LlavaHIP
+    from multimodal_unlearning_amd.synthetic import bench_batch, make_forget_batch
+    from multimodal_unlearning_amd.trainer import MMTrainerForgetting
+
+    rank, local, world = init_distributed()
+    assert world == args.gpus or world == 1 and args.gpus == 1, f"launched {world} ranks for --gpus {args.gpus}"
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback for the HIP path)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    cfg = {"7b": llava_1_5_7b, "13b": llava_1_5_13b, "tiny": tiny_test_config}[args.model]()
+    if args.layers:
+        cfg.text.num_layers = args.layers
+    model = LlavaHIP(cfg, device=dev, init="device", seed=0)
+    needs_teacher = any(k in args.loss.lower() for k in ("kl", "npo", "scrub", "dpo", "llmu"))
+    teacher = LlavaHIP(cfg, device=dev, init="device", seed=1, trainable=False) if needs_teacher else None
+    splits = ("forget", "retain", "idk") if any(k in args.loss.lower() for k in ("idk", "dpo", "llmu")) else ("forget", "retain")
+    tr = MMTrainerForgetting(model=model, forget_loss=args.loss, teacher_model=teacher, loss_beta=1.0, l1_lambda=0.0,
+                             l0_lambda=0.0, l_norm_from="zero", loss_args={"fuse_pairs": not args.no_fuse})
+    fcfg = ForgetConfig(batch_size=args.micro_batch, gradient_accumulation_steps=args.grad_accum)
+    eng = ForgetEngine(model, tr, fcfg, total_steps=args.steps + args.warmup + 1, warmup_steps=1)
+
+    B, GA = args.micro_batch, args.grad_accum
+    if args.model == "tiny":
+        S = 64
+        mbs = [make_forget_batch(cfg, B, S, seed=1234 + rank * 100 + i, n_question=8, splits=splits, device=dev)
+               for i in range(GA)]
+    else:
+        S = cfg.vision.num_patches + 512
+        mbs = [bench_batch(cfg, B, seed=1234 + rank * 100 + i, splits=splits, device=dev) for i in range(GA)]
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.step(mbs)
+    sync()
+    t0 = time.perf_counter()
+    timer = None
+    for k in range(args.steps):
+        if k == args.steps - 1 and rank == 0:
+            timer = GemmTimer(hip)
+            with timer:
+                eng.step(mbs)
+        else:
+            eng.step(mbs)
+    sync()
+    elapsed = time.perf_counter() - t0
+    tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+
+    if rank == 0:
+        samples = world * B * GA * args.steps
+        value = samples / elapsed
+        fps = flops_per_sample(cfg, S)
+        f, t, n, by = timer.summary()
+        out = {
+            "metric": "forget-step samples/sec (img+text pairs) LLaVA-1.5-7B grad_diff",
+            "value": round(value, 4), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"LLaVA-1.5-{args.model} {args.loss} full-FT (CLIP frozen), S={S} (576 image + 512 text "
+                                   f"tokens), image 336, random-init weights", "micro_batch_pairs_per_gpu": B,
+                       "grad_accum": GA, "global_batch": world * B * GA, "seq_len": S, "parallelism": f"dp{world}",
+                       "paired_fusion": not args.no_fuse, "optimizer": "AdamW fp32 moments, clip 1.0",
+                       "decoder_layers": cfg.text.num_layers},
+            "step_tflops_per_gpu": round(value * fps / world / 1e12, 1),
+            "step_frac_of_mfma_peak": round(value * fps / world / PEAK_BF16, 4),
+            "roofline": {"bound": "mfma", "achieved": round(f / t / 1e12, 1), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
+                         "frac": round(f / t / PEAK_BF16, 4), "traffic": None, "kernel": "gemm_bf16_kernel (all layouts)",
+                         "launches": n, "avg_launch_us": round(t / n * 1e6, 1),
+                         "gemm_share_of_step": round(t / (elapsed / args.steps), 3), "by_layout": by},
+        }
+        if not args.no_cpu_baseline and args.model != "tiny":
+            out["cpu_baseline"] = cpu_baseline(cfg, S)
+        elif args.model == "tiny":
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

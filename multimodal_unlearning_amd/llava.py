@@ -136,7 +136,7 @@ def row_loss_sum(student_logits, teacher_logits, mode, beta=1.0):
 # --------------------------------------------------------------------------------------------------------
 class LlavaHIP(nn.Module):
     def __init__(self, cfg: LlavaConfig, params: Optional[Dict[str, torch.Tensor]] = None, device="cuda:0",
-                 seed: int = 0, freeze_vision: bool = True, trainable: bool = True):
+                 seed: int = 0, freeze_vision: bool = True, trainable: bool = True, init: str = "numpy"):
         super().__init__()
         if not freeze_vision:
             raise NotImplementedError("the vision tower is frozen in the forget step (mm/forget.py:117-118)")
@@ -165,9 +165,12 @@ class LlavaHIP(nn.Module):
             self.w[name] = base[off:off + math.prod(shape)].view(shape)
         self._grad_flat: Optional[torch.Tensor] = None
         self.g: Dict[str, torch.Tensor] = OrderedDict()
-        if params is None:
-            params = init_params(cfg, seed=seed)
-        self.load_params(params)
+        if params is not None:
+            self.load_params(params)
+        elif init == "device":
+            self.init_random_(seed)
+        else:
+            self.load_params(init_params(cfg, seed=seed))
         # rope tables + scratch
         t = cfg.text
         self._cos = torch.empty(t.max_position, t.head_dim // 2, device=dev, dtype=BF)
@@ -184,6 +187,19 @@ class LlavaHIP(nn.Module):
     @property
     def device(self):
         return self.train_flat.device
+
+    def init_random_(self, seed: int = 0, std: float = 0.02):
+        """Random-init weights of the architecture, generated ON DEVICE (7B/13B: no host copy): N(0, std^2) for
+        matrices / embeddings / biases, 1 for every norm weight (SURVEY.md §8d synthetic weights)."""
+        gen = torch.Generator(device=self.device).manual_seed(seed)
+        with torch.no_grad():
+            for flat in (self.frozen_flat, self.train_flat.data):
+                if flat.numel():
+                    flat.normal_(0.0, std, generator=gen)
+            for name, t in self.w.items():
+                if name.endswith(("norm.weight", "ln1.weight", "ln2.weight", "pre_ln.weight")):
+                    t.fill_(1.0)
+            self.w["vision.patch_embed.weight"][:, self.cfg.vision.patch_k:] = 0
 
     def load_params(self, params: Dict[str, torch.Tensor]):
         with torch.no_grad():
