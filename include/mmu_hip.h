@@ -27,6 +27,9 @@ int mmu_abi_version(void);
  *      (the rounding points of transformers' bf16 modules); accumulate=1: C = bf16(float(C) + acc). */
 int mmu_gemm_bf16(int layout, const void* A, const void* B, void* C, const void* bias, const void* resid,
                   int M, int N, int K, int lda, int ldb, int ldc, int ldr, int act, int accumulate, void* stream);
+/* Tile configuration override (A/B tests, tuning): 0 = heuristic, 128 = 128x128x64 4-wave kernel,
+ * 256 = 256x256x64 8-wave 8-phase kernel.  Process-wide. */
+int mmu_gemm_set_tile(int tile);
 
 /* ---- Attention (replaces the flash-attn wheel: mm/forget.py:86,98,106 attn_implementation=
  * "flash_attention_2"; SURVEY §8a K3 (CLIP, non-causal, head_dim 64) and K10 (Llama, causal, 128)) ----

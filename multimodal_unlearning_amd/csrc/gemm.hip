@@ -92,6 +92,43 @@ __device__ __forceinline__ float act_apply(float v, int act) {
     return v;
 }
 
+// Store 4 consecutive n of row m.  EPI 0: plain bf16 store; 1: bias / activation / residual with the bf16
+// rounding points of the HF modules; 2: accumulate into C (gradient accumulation).
+template <int EPI>
+__device__ __forceinline__ void epi_store(const GemmArgs& p, int m, int n, const f32x4 v) {
+    if (m >= p.M || n >= p.N) return;  // N % 8 == 0 is enforced by the host wrapper
+    bf16* cp = p.C + (size_t)m * p.ldc + n;
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = v[j];
+    if (EPI == 1) {
+        if (p.bias) {
+            const bf16x4 b = *reinterpret_cast<const bf16x4*>(p.bias + n);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] += bf2f(b[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = round_bf16(o[j]);
+        if (p.act) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = round_bf16(act_apply(o[j], p.act));
+        }
+        if (p.resid) {
+            const bf16x4 r = *reinterpret_cast<const bf16x4*>(p.resid + (size_t)m * p.ldr + n);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] += bf2f(r[j]);
+        }
+    } else if (EPI == 2) {
+        const bf16x4 c = *reinterpret_cast<const bf16x4*>(cp);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] += bf2f(c[j]);
+    }
+    bf16x4 out;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) out[j] = f2bf(o[j]);
+    *reinterpret_cast<bf16x4*>(cp) = out;
+}
+
 template <bool AT, bool BT, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -153,46 +190,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
     }
 
     // Epilogue: acc[nt][mt][j] = C[m = m0+wm*64+mt*16+(lane&15)][n = n0+wn*64+nt*16+4*(lane>>4)+j]
-    // EPI 0: plain bf16 store; 1: bias / activation / residual; 2: accumulate into C (grad accumulation).
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
         const int m = m0 + wm * 64 + mt * 16 + (lane & 15);
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             const int n = n0 + wn * 64 + nt * 16 + 4 * (lane >> 4);
-            if (m >= p.M || n >= p.N) continue;  // N % 8 == 0 is enforced by the host wrapper
-            const f32x4 v = acc[nt][mt];
-            bf16* cp = p.C + (size_t)m * p.ldc + n;
-            float o[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = v[j];
-            if (EPI == 1) {
-                if (p.bias) {
-                    const bf16x4 b = *reinterpret_cast<const bf16x4*>(p.bias + n);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] += bf2f(b[j]);
-                }
-                // HF rounds the Linear output to bf16 before the activation / residual add; keep that order.
-#pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = round_bf16((o[j]));
-                if (p.act) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = round_bf16((act_apply(o[j], p.act)));
-                }
-                if (p.resid) {
-                    const bf16x4 r = *reinterpret_cast<const bf16x4*>(p.resid + (size_t)m * p.ldr + n);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] += bf2f(r[j]);
-                }
-            } else if (EPI == 2) {
-                const bf16x4 c = *reinterpret_cast<const bf16x4*>(cp);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] += bf2f(c[j]);
-            }
-            bf16x4 out;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) out[j] = f2bf(o[j]);
-            *reinterpret_cast<bf16x4*>(cp) = out;
+            epi_store<EPI>(p, m, n, acc[nt][mt]);
         }
     }
 }
@@ -220,7 +224,291 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
     return launch_gemm_epi<AT, BT, 0>(a, stream);
 }
 
+
+// =================================================================================================
+// 256x256x64 tile, 512 threads = 8 waves (2 M x 4 N), wave output 128x64, 8 phases per 2 K-tiles.
+//
+// Each wave's 128x64 output is four quadrants (a,b) = (64-row block a) x (32-col block b); one phase computes
+// one quadrant for one K-tile (16 MFMA 16x16x32).  The LDS holds, per K-tile buffer d (2 of them), four
+// 16-KiB HALF-TILES defined by those blocks, not by contiguous rows:
+//     A-h[a]: local row wm*64 + i  <->  tile row wm*128 + a*64 + i      (i < 64, both wm)
+//     B-h[b]: local row wn*32 + j  <->  tile col (wn>>1)*128 + b*64 + (wn&1)*32 + j   (j < 32, all four wn)
+// so a half-tile is read in exactly ONE phase (A-h0,B-h0: phase 1; B-h1: 2; A-h1: 3; none: 4) and can be
+// restaged one phase later.  Every phase issues the LDS-DMA of one future half-tile (2 x 16-B per lane):
+//     ph1 A-h1(t1)->d1 | ph2 B-h0(t0+2)->d0 | ph3 A-h0(t0+2)->d0 | ph4 B-h1(t0+2)->d0, vmcnt(6)
+//     ph5 A-h1(t0+2)->d0 | ph6 B-h0(t1+2)->d1 | ph7 A-h0(t1+2)->d1 | ph8 B-h1(t1+2)->d1, vmcnt(6)
+// The wm=1 waves run ONE BARRIER BEHIND the wm=0 waves (stagger), so each SIMD always has one wave in its MFMA
+// cluster while its partner issues LDS reads / LDS-DMA.
+// WAR (with the stagger): a half-tile is restaged >= 2 phases after the phase that read it, or 1 phase after
+// when its reads were retired by the counted lgkmcnt(8) BEFORE that phase's first barrier (B-h0: read first in
+// phases 1/5, restaged in phases 2/6).
+// RAW: the counted vmcnt(6) of phase 4 (8) leaves the 3 youngest half-tiles in flight and retires all of
+// K-tile t1 (t0+2); it sits before that phase's first barrier and the tile is first read one phase later.
+// vmcnt is never 0 inside the loop.  K-tiles past the end (odd tile count, prefetch overrun) read the zero page.
+// =================================================================================================
+namespace g256 {
+
+constexpr int HB = 16384;  // bytes per half-tile
+constexpr int LDS_BYTES = 8 * HB;
+
+// local row/col of a half-tile -> row/col of the 256-wide tile: 64-element runs stay contiguous so that a K-major
+// half-tile is fetched in whole 128-B lines.
+__device__ __forceinline__ int a_map(int r) { return ((r >> 6) << 7) + (r & 63); }  // + a*64
+__device__ __forceinline__ int b_map(int r) { return ((r >> 6) << 7) + (r & 63); }  // + b*64
+
+// per-thread staging descriptors for one half-tile kind: 2 LDS-DMA instructions
+struct StageDesc {
+    const bf16* src[2];  // source at k0 = 0 (nullptr: row/col out of range -> zero page)
+    int kofs[2];         // element offset along K of this lane's chunk (K-contiguous) or k row (K-major)
+};
+
+template <bool T, bool IS_A>
+__device__ __forceinline__ StageDesc make_desc(const bf16* G, int ld, int base0, int sub, int dim, int wave, int lane) {
+    StageDesc d;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int t = wave * 2 + i;
+        if (!T) {
+            const int r = t * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ (r & 7);
+            const int g = base0 + (IS_A ? a_map(r) : b_map(r)) + sub * 64;
+            d.kofs[i] = c * 8;
+            d.src[i] = (g < dim) ? (G + (size_t)g * ld + c * 8) : nullptr;
+        } else {
+            const int kr = t * 4 + (lane >> 4);
+            const int c = (lane & 15) ^ swzT(kr);
+            const int lc = c * 8;
+            const int g = base0 + (IS_A ? a_map(lc) : b_map(lc)) + sub * 64;
+            d.kofs[i] = kr;
+            d.src[i] = (g < dim) ? (G + (size_t)kr * ld + g) : nullptr;
+        }
+    }
+    return d;
+}
+
+template <bool T>
+__device__ __forceinline__ void stage_half(char* dst, const StageDesc& d, int ld, int k0, int Kd, int wave) {
+    const bf16* zero = reinterpret_cast<const bf16*>(mmu_zero16);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const bool ok = d.src[i] != nullptr && (k0 + d.kofs[i] < Kd);
+        const bf16* s = ok ? (T ? d.src[i] + (size_t)k0 * ld : d.src[i] + k0) : zero;
+        glds16(s, dst + (wave * 2 + i) * 1024);
+    }
+}
+
+template <bool AT, bool BT, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    int pid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = pid & 7, loc = pid >> 3;
+        pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    constexpr int GROUP_M = 4;
+    const int per_group = GROUP_M * p.tiles_n;
+    const int gid = pid / per_group;
+    const int first_m = gid * GROUP_M;
+    const int gsz = min(p.tiles_m - first_m, GROUP_M);
+    const int tile_m = first_m + (pid % per_group) % gsz;
+    const int tile_n = (pid % per_group) / gsz;
+    const int m0 = tile_m * 256, n0 = tile_n * 256;
+
+    // LDS map: buffer d in {0,1}: [A-h0 | A-h1 | B-h0 | B-h1], 16 KiB each
+    auto buf = [&](int d, int op, int h) -> char* { return smem + ((d * 2 + op) * 2 + h) * HB; };
+
+    const StageDesc dA0 = make_desc<AT, true>(p.A, p.lda, m0, 0, p.M, wave, lane);
+    const StageDesc dA1 = make_desc<AT, true>(p.A, p.lda, m0, 1, p.M, wave, lane);
+    const StageDesc dB0 = make_desc<BT, false>(p.B, p.ldb, n0, 0, p.N, wave, lane);
+    const StageDesc dB1 = make_desc<BT, false>(p.B, p.ldb, n0, 1, p.N, wave, lane);
+
+    f32x4 acc[2][2][2][4];  // [a][b][nt][mt]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) acc[a][b][nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    bf16x8 fa[2][4];     // [ks][mt]   current A block
+    bf16x8 fb[2][2][2];  // [b][ks][nt]
+
+    const int nk = (p.K + 63) / 64;
+    const int niter = (nk + 1) / 2;
+
+#define G256_BAR()                               \
+    do {                                         \
+        __builtin_amdgcn_sched_barrier(0);       \
+        __builtin_amdgcn_s_barrier();            \
+        __builtin_amdgcn_sched_barrier(0);       \
+    } while (0)
+#define G256_LGKM8()                                   \
+    do {                                               \
+        __builtin_amdgcn_sched_barrier(0);             \
+        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"); \
+    } while (0)
+#define G256_STAGE_A(desc, d, h, kt) stage_half<AT>(buf(d, 0, h), desc, p.lda, (kt) * 64, p.K, wave)
+#define G256_STAGE_B(desc, d, h, kt) stage_half<BT>(buf(d, 1, h), desc, p.ldb, (kt) * 64, p.K, wave)
+#define G256_READ_A(d, a)                                                                                  \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)    \
+        fa[ks][mt] = read_frag<AT>((const MMU_LDS char*)buf(d, 0, a), wm * 64 + mt * 16, ks, lane)
+#define G256_READ_B(d, b)                                                                                  \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)    \
+        fb[b][ks][nt] = read_frag<BT>((const MMU_LDS char*)buf(d, 1, b), wn * 32 + nt * 16, ks, lane)
+#define G256_MMA(a, b)                                                                                      \
+    do {                                                                                                    \
+        __builtin_amdgcn_s_setprio(1);                                                                      \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)  \
+            _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) acc[a][b][nt][mt] =                            \
+                __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[b][ks][nt], fa[ks][mt], acc[a][b][nt][mt], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                                      \
+    } while (0)
+
+    // prologue: K-tile 0 complete in d0; B-h0, A-h0, B-h1 of K-tile 1 in flight towards d1
+    G256_STAGE_A(dA0, 0, 0, 0);
+    G256_STAGE_B(dB0, 0, 0, 0);
+    G256_STAGE_B(dB1, 0, 1, 0);
+    G256_STAGE_A(dA1, 0, 1, 0);
+    G256_STAGE_B(dB0, 1, 0, 1);
+    G256_STAGE_A(dA0, 1, 0, 1);
+    G256_STAGE_B(dB1, 1, 1, 1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    G256_BAR();
+    // Stagger: the wm=1 waves (the second wave of every SIMD) run one barrier behind the wm=0 waves, so on each
+    // SIMD one wave is in its MFMA cluster while the other issues its LDS reads / LDS-DMA.
+    if (wm == 1) G256_BAR();
+
+    for (int it = 0; it < niter; ++it) {
+        const int t0 = 2 * it, t1 = t0 + 1;
+        // ---- phase 1: B reads first so lgkmcnt(8) retires them before the barrier (B-h0 is restaged in phase 2)
+        G256_READ_B(0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        G256_READ_A(0, 0);
+        G256_STAGE_A(dA1, 1, 1, t1);
+        G256_LGKM8();
+        G256_BAR();
+        G256_MMA(0, 0);
+        G256_BAR();
+        // ---- phase 2
+        G256_READ_B(0, 1);
+        G256_STAGE_B(dB0, 0, 0, t0 + 2);
+        G256_BAR();
+        G256_MMA(0, 1);
+        G256_BAR();
+        // ---- phase 3
+        G256_READ_A(0, 1);
+        G256_STAGE_A(dA0, 0, 0, t0 + 2);
+        G256_BAR();
+        G256_MMA(1, 1);
+        G256_BAR();
+        // ---- phase 4
+        G256_STAGE_B(dB1, 0, 1, t0 + 2);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        G256_BAR();
+        G256_MMA(1, 0);
+        G256_BAR();
+        // ---- phase 5
+        G256_READ_B(1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        G256_READ_A(1, 0);
+        G256_STAGE_A(dA1, 0, 1, t0 + 2);
+        G256_LGKM8();
+        G256_BAR();
+        G256_MMA(0, 0);
+        G256_BAR();
+        // ---- phase 6
+        G256_READ_B(1, 1);
+        G256_STAGE_B(dB0, 1, 0, t1 + 2);
+        G256_BAR();
+        G256_MMA(0, 1);
+        G256_BAR();
+        // ---- phase 7
+        G256_READ_A(1, 1);
+        G256_STAGE_A(dA0, 1, 0, t1 + 2);
+        G256_BAR();
+        G256_MMA(1, 1);
+        G256_BAR();
+        // ---- phase 8
+        G256_STAGE_B(dB1, 1, 1, t1 + 2);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        G256_BAR();
+        G256_MMA(1, 0);
+        G256_BAR();
+    }
+    if (wm == 0) G256_BAR();  // balance the stagger barrier
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the overrun prefetches before the LDS is released
+
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int m = m0 + wm * 128 + a * 64 + mt * 16 + (lane & 15);
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const int n = n0 + (wn >> 1) * 128 + b * 64 + (wn & 1) * 32 + nt * 16 + 4 * (lane >> 4);
+                    epi_store<EPI>(p, m, n, acc[a][b][nt][mt]);
+                }
+        }
+#undef G256_BAR
+#undef G256_LGKM8
+#undef G256_STAGE_A
+#undef G256_STAGE_B
+#undef G256_READ_A
+#undef G256_READ_B
+#undef G256_MMA
+}
+
+template <bool AT, bool BT, int EPI>
+int launch_epi(GemmArgs a, hipStream_t stream) {
+    static bool configured = false;
+    auto kern = gemm256_kernel<AT, BT, EPI>;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        configured = true;
+    }
+    a.tiles_m = (a.M + 255) / 256;
+    a.tiles_n = (a.N + 255) / 256;
+    hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(512), LDS_BYTES, stream, a);
+    MMU_CHECK_LAUNCH();
+    return 0;
+}
+
+template <bool AT, bool BT>
+int launch(const GemmArgs& a, hipStream_t stream) {
+    if (a.accumulate) return launch_epi<AT, BT, 2>(a, stream);
+    if (a.bias || a.resid || a.act) return launch_epi<AT, BT, 1>(a, stream);
+    return launch_epi<AT, BT, 0>(a, stream);
+}
+
+}  // namespace g256
+
 }  // namespace
+
+static int g_force_tile = 0;
+
+// 256^2 tiles (8-phase kernel) when the grid fills the 256 CUs reasonably; the 128^2 kernel (2 blocks/CU)
+// otherwise.  Wave quantisation: cost ~ rounds * work per CU per round / rate; a 256^2 tile is 4 units at a
+// measured ~1.45x per-CU rate, the 128^2 kernel runs 2 one-unit tiles per CU per round.
+static bool pick_256(int M, int N, int K) {
+    if (g_force_tile == 256) return true;
+    if (g_force_tile == 128) return false;
+    if (K < 256) return false;
+    const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
+    const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+    const double c256 = (double)((t256 + 255) / 256) * (4.0 / 1.45);
+    const double c128 = (double)((t128 + 511) / 512) * 2.0;
+    return c256 <= c128;
+}
 
 // C-ABI. layout: 0 = NT (A[M,K], B[N,K]); 1 = NN (A[M,K], B[K,N]); 2 = TN (A[K,M], B[K,N]).
 // Returns 0, a hipError_t, or -1 for an argument the kernel does not support.
@@ -241,10 +529,25 @@ extern "C" int mmu_gemm_bf16(int layout, const void* A, const void* B, void* C, 
     a.act = act; a.accumulate = accumulate;
     a.tiles_m = (M + BM - 1) / BM; a.tiles_n = (N + BN - 1) / BN;
     hipStream_t s = (hipStream_t)stream;
+    if (pick_256(M, N, K)) {
+        switch (layout) {
+            case 0: return g256::launch<false, false>(a, s);
+            case 1: return g256::launch<false, true>(a, s);
+            case 2: return g256::launch<true, true>(a, s);
+            default: return -1;
+        }
+    }
     switch (layout) {
         case 0: return launch_gemm<false, false>(a, s);
         case 1: return launch_gemm<false, true>(a, s);
         case 2: return launch_gemm<true, true>(a, s);
         default: return -1;
     }
+}
+
+// Tile-config override for A/B tests: 0 = heuristic, 128 / 256 = force that kernel.
+extern "C" int mmu_gemm_set_tile(int tile) {
+    if (tile != 0 && tile != 128 && tile != 256) return -1;
+    g_force_tile = tile;
+    return 0;
 }

@@ -21,6 +21,7 @@ _vp, _i, _f, _ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
 SIGNATURES = {
     "mmu_abi_version": [],
     "mmu_gemm_bf16": [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "mmu_gemm_set_tile": [_i],
     "mmu_attn_fwd": [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp],
     "mmu_attn_bwd": [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i,
                      _vp],
@@ -123,6 +124,11 @@ def gemm(layout: int, A, B, out, *, bias=None, resid=None, act=0, accumulate=Fal
                               _stream())
     _check(rc, "mmu_gemm_bf16")
     return out
+
+
+def gemm_set_tile(tile: int):
+    """0 = heuristic, 128 / 256 = force that tile configuration (process-wide)."""
+    _check(load().mmu_gemm_set_tile(int(tile)), "mmu_gemm_set_tile")
 
 
 # ------------------------------------------------------------------------------------------- attention

@@ -32,12 +32,21 @@ def _relerr(a, b):
 
 
 # ------------------------------------------------------------------------------------------------ GEMM
-GEMM_SHAPES = [(128, 128, 64), (256, 384, 192), (300, 136, 200), (77, 8, 24), (2176, 512, 1024), (130, 264, 72)]
+GEMM_SHAPES = [(128, 128, 64), (256, 384, 192), (300, 136, 200), (77, 8, 24), (2176, 512, 1024), (130, 264, 72),
+               (512, 768, 448), (1000, 520, 4096)]
 
 
+@pytest.fixture(autouse=True)
+def _reset_tile():
+    yield
+    hip.gemm_set_tile(0)
+
+
+@pytest.mark.parametrize("tile", [128, 256])
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
 @pytest.mark.parametrize("layout", [hip.NT, hip.NN, hip.TN])
-def test_gemm_exact_integer(dev, layout, M, N, K):
+def test_gemm_exact_integer(dev, layout, M, N, K, tile):
+    hip.gemm_set_tile(tile)
     if layout == hip.TN and M % 8:
         M = (M + 7) // 8 * 8
     a = _rand_int((M, K), dev, seed=1)  # logical A [M,K]
@@ -52,7 +61,9 @@ def test_gemm_exact_integer(dev, layout, M, N, K):
     assert bad.numel() == 0, f"layout {layout} {M}x{N}x{K}: {bad.shape[0]} mismatches, first {bad[:5].tolist()}"
 
 
-def test_gemm_epilogues(dev):
+@pytest.mark.parametrize("tile", [128, 256])
+def test_gemm_epilogues(dev, tile):
+    hip.gemm_set_tile(tile)
     M, N, K = 200, 264, 128
     a = _randn((M, K), dev, 0.5, 3)
     w = _randn((N, K), dev, 0.5, 4)
