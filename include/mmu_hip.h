@@ -65,6 +65,8 @@ int mmu_swiglu_bwd(const void* gate_up, const void* dh, void* dgate_up, int M, i
 int mmu_gelu_fwd(const void* x, void* y, long long n, void* stream);
 int mmu_gelu_bwd(const void* x, const void* dy, void* dx, long long n, void* stream);
 int mmu_add_bf16(const void* a, const void* b, void* out, long long n, void* stream);
+/* dst[C][R] = src[R][C]^T: keeps W^T resident so dgrad runs on the NT GEMM path. */
+int mmu_transpose_bf16(const void* src, void* dst, int R, int C, void* stream);
 int mmu_colsum_nparts(int M); /* part must hold nparts*d floats */
 int mmu_colsum_bf16(const void* x, float* part, void* dst, int accumulate, int M, int d, void* stream);
 

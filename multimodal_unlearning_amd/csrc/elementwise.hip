@@ -486,6 +486,35 @@ __global__ void embed_flush_kernel(float* __restrict__ scratch, int* __restrict_
     }
 }
 
+
+// Tiled bf16 transpose: dst[c][r] = src[r][c]; 64x64 tiles through LDS, 16-B global accesses both ways.
+__global__ __launch_bounds__(256) void transpose_kernel(const bf16* __restrict__ src, bf16* __restrict__ dst, int R,
+                                                        int C) {
+    __shared__ bf16 tile[64][72];  // +8 pad: 144-B rows keep 16-B alignment and spread banks
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tr = threadIdx.x >> 3, tc = (threadIdx.x & 7) * 8;  // 32 rows x 8 chunks per pass
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int r = r0 + tr + p * 32, c = c0 + tc;
+        bf16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = f2bf(0.f);
+        if (r < R && c < C) v = *reinterpret_cast<const bf16x8*>(src + (size_t)r * C + c);
+        *reinterpret_cast<bf16x8*>(&tile[tr + p * 32][tc]) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int c = c0 + tr + p * 32, r = r0 + tc;  // output row = source column
+        if (c < C && r < R) {
+            bf16x8 v;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = tile[tc + j][tr + p * 32];
+            *reinterpret_cast<bf16x8*>(dst + (size_t)c * R + r) = v;
+        }
+    }
+}
+
 inline int grid_for(size_t work_items, int block) {
     size_t g = (work_items + block - 1) / block;
     if (g > 2048) g = 2048;  // 256 CUs x 8 blocks, grid-stride the rest
@@ -697,5 +726,14 @@ extern "C" int mmu_embed_bwd(const long long* ids, const int* slot, const void* 
         hipLaunchKernelGGL(embed_flush_kernel, dim3(2048), dim3(256), 0, s, scratch, flag, (bf16*)grad_table, vocab, d);
         MMU_CHECK_LAUNCH();
     }
+    return 0;
+}
+
+// dst[C][R] = src[R][C]^T (R, C multiples of 8).  Used to keep W^T resident for the NT dgrad path.
+extern "C" int mmu_transpose_bf16(const void* src, void* dst, int R, int C, void* stream) {
+    if (R <= 0 || C <= 0 || (R & 7) || (C & 7)) return -1;
+    hipLaunchKernelGGL(transpose_kernel, dim3((C + 63) / 64, (R + 63) / 64), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16*)src, (bf16*)dst, R, C);
+    MMU_CHECK_LAUNCH();
     return 0;
 }

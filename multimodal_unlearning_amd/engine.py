@@ -82,7 +82,7 @@ class ForgetEngine:
     """engine.step(micro_batches) = GA x (compute_loss -> backward) -> all-reduce -> clip -> AdamW -> zero grads."""
 
     def __init__(self, model, trainer, cfg: ForgetConfig, total_steps: int = 1000, warmup_steps: int = 0,
-                 group=None):
+                 group=None, transposed_weights: bool = True):
         from . import hip  # HIP optimiser kernels; fails loudly when the library is missing
 
         self.hip = hip
@@ -98,6 +98,8 @@ class ForgetEngine:
         self.sumsq = torch.zeros(1, device=dev, dtype=torch.float32)
         self.opt_step = 0
         self.reducer = GradBucketReducer(self.grad, group)
+        if transposed_weights:
+            model.enable_transposed_weights()
 
     def step(self, micro_batches: List[Dict], sync_loss: bool = False) -> StepStats:
         ga = len(micro_batches)
@@ -119,6 +121,8 @@ class ForgetEngine:
         self.hip.adamw(model.train_flat.data, self.grad, self.m, self.v, lr, self.cfg.adam_beta1, self.cfg.adam_beta2,
                        self.cfg.adam_eps, self.cfg.weight_decay, self.opt_step, self.sumsq, self.cfg.max_grad_norm,
                        1.0 / self.world, True)
+        if model.wT:
+            model.refresh_transposed_weights()
         mean_loss = (total / ga)
         if sync_loss:
             if self.world > 1:

@@ -38,6 +38,7 @@ SIGNATURES = {
     "mmu_gelu_fwd": [_vp, _vp, _ll, _vp],
     "mmu_gelu_bwd": [_vp, _vp, _vp, _ll, _vp],
     "mmu_add_bf16": [_vp, _vp, _vp, _ll, _vp],
+    "mmu_transpose_bf16": [_vp, _vp, _i, _i, _vp],
     "mmu_colsum_nparts": [_i],
     "mmu_colsum_bf16": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "mmu_image_slots": [_vp, _i, _ll, _vp, _vp, _vp],
@@ -238,6 +239,14 @@ def add(a, b, out):
     _bf16c(a, b, out)
     _check(load().mmu_add_bf16(_p(a), _p(b), _p(out), a.numel(), _stream()), "mmu_add_bf16")
     return out
+
+
+def transpose(src, dst):
+    _bf16c(src, dst)
+    R, Cc = src.shape
+    assert src.is_contiguous() and dst.is_contiguous() and tuple(dst.shape) == (Cc, R)
+    _check(load().mmu_transpose_bf16(_p(src), _p(dst), R, Cc, _stream()), "mmu_transpose_bf16")
+    return dst
 
 
 def colsum_nparts(M):

@@ -182,6 +182,9 @@ class LlavaHIP(nn.Module):
         # backward (used by the DP engine to start the RCCL all-reduce of a bucket while backward continues)
         self.grad_ready_hook: Optional[Callable[[int, int], None]] = None
         self.capture_layer: Optional[int] = None
+        # optional resident W^T copies of the decoder / lm_head weights (dgrad on the NT GEMM path)
+        self.wT: Dict[str, torch.Tensor] = {}
+        self._wT_flat: Optional[torch.Tensor] = None
 
     # ------------------------------------------------------------------------------------------ params
     @property
@@ -220,6 +223,40 @@ class LlavaHIP(nn.Module):
         lo = self._off[f"text.layers.{i}.input_norm.weight"][1]
         hi = self.range_of(f"text.layers.{i}.down.weight")[1]
         return lo, hi
+
+    # -------------------------------------------------------------------------- transposed weight copies
+    def _dgrad_weight_names(self):
+        names = []
+        for i in range(self.cfg.text.num_layers):
+            p = f"text.layers.{i}."
+            names += [p + "qkv.weight", p + "o.weight", p + "gate_up.weight", p + "down.weight"]
+        return names + ["lm_head.weight"]
+
+    def enable_transposed_weights(self):
+        """Keep W^T of every decoder Linear + lm_head resident (+13.5 GB at 7B; 288 GB HBM) so that dgrad
+        dX = dY W runs as an NT GEMM (both operands reduction-contiguous) instead of reading W reduction-major.
+        The owner of the optimiser step must call refresh_transposed_weights() after every weight update
+        (ForgetEngine does); a stale copy silently gives stale gradients, hence opt-in."""
+        if self._wT_flat is None:
+            names = self._dgrad_weight_names()
+            total = sum(self.w[n].numel() for n in names)
+            self._wT_flat = torch.empty(total, device=self.device, dtype=BF)
+            off = 0
+            for n in names:
+                r, c = self.w[n].shape
+                self.wT[n] = self._wT_flat[off:off + r * c].view(c, r)
+                off += r * c
+        self.refresh_transposed_weights()
+
+    def refresh_transposed_weights(self):
+        for n, t in self.wT.items():
+            hip.transpose(self.w[n], t)
+
+    def _dgrad(self, dy, name, out):
+        """out = dy @ W[name]  (dX of y = x W^T)."""
+        if name in self.wT:
+            return hip.gemm(hip.NT, dy, self.wT[name], out)
+        return hip.gemm(hip.NN, dy, self.w[name], out)
 
     def ensure_grad(self):
         """Attach the persistent flat gradient buffer as train_flat.grad (zeroed when (re)attached)."""
@@ -390,7 +427,7 @@ class LlavaHIP(nn.Module):
         hip.rmsnorm_fwd(h, w["text.norm.weight"], y, None, t.rms_norm_eps)
         hip.gemm(hip.TN, dlog, y, g["lm_head.weight"], accumulate=True)
         dy = torch.empty(M, dt, device=dev, dtype=BF)
-        hip.gemm(hip.NN, dlog, w["lm_head.weight"], dy)
+        self._dgrad(dlog, "lm_head.weight", dy)
         dh = torch.empty(M, dt, device=dev, dtype=BF)
         hip.rmsnorm_bwd(dy, h, w["text.norm.weight"], rstdf, None, dh, dw_part, g["text.norm.weight"], True)
         if hook:
@@ -406,20 +443,20 @@ class LlavaHIP(nn.Module):
             hip.swiglu_fwd(gu, act)
             hip.gemm(hip.TN, dh, act, g[p + "down.weight"], accumulate=True)
             dact = torch.empty(M, I, device=dev, dtype=BF)
-            hip.gemm(hip.NN, dh, w[p + "down.weight"], dact)
+            self._dgrad(dh, p + "down.weight", dact)
             dgu = torch.empty(M, 2 * I, device=dev, dtype=BF)
             hip.swiglu_bwd(gu, dact, dgu)
             del act, dact, gu
             hip.rmsnorm_fwd(h2, w[p + "post_norm.weight"], y, None, t.rms_norm_eps)
             hip.gemm(hip.TN, dgu, y, g[p + "gate_up.weight"], accumulate=True)
-            hip.gemm(hip.NN, dgu, w[p + "gate_up.weight"], dy)
+            self._dgrad(dgu, p + "gate_up.weight", dy)
             del dgu
             dh2 = torch.empty(M, dt, device=dev, dtype=BF)
             hip.rmsnorm_bwd(dy, h2, w[p + "post_norm.weight"], rstd2, dh, dh2, dw_part, g[p + "post_norm.weight"], True)
             # attention
             hip.gemm(hip.TN, dh2, a, g[p + "o.weight"], accumulate=True)
             da = dh  # reuse the buffer of the (now consumed) upstream gradient
-            hip.gemm(hip.NN, dh2, w[p + "o.weight"], da)
+            self._dgrad(dh2, p + "o.weight", da)
             dqkv = torch.empty(M, 3 * dt, device=dev, dtype=BF)
             hip.attn_bwd(qkv[:, :dt], qkv[:, dt:2 * dt], qkv[:, 2 * dt:], a, lse, saved["kmask"], da, delta,
                          dqkv[:, :dt], dqkv[:, dt:2 * dt], dqkv[:, 2 * dt:], B, S, H, D, scale, True)
@@ -427,7 +464,7 @@ class LlavaHIP(nn.Module):
             del qkv, a
             hip.rmsnorm_fwd(hin, w[p + "input_norm.weight"], y, None, t.rms_norm_eps)
             hip.gemm(hip.TN, dqkv, y, g[p + "qkv.weight"], accumulate=True)
-            hip.gemm(hip.NN, dqkv, w[p + "qkv.weight"], dy)
+            self._dgrad(dqkv, p + "qkv.weight", dy)
             del dqkv
             dh = da  # overwrite: da is dead after attn_bwd
             hip.rmsnorm_bwd(dy, hin, w[p + "input_norm.weight"], rstd1, dh2, dh, dw_part, g[p + "input_norm.weight"],

@@ -490,3 +490,11 @@ def test_adamw_and_gradnorm(dev):
     y = x.clone()
     hip.scale_(y, 0.25)
     assert (y == (x.float() * 0.25).to(BF)).all()
+
+
+def test_transpose(dev):
+    for R, Cc in [(64, 64), (200, 136), (4096, 1032), (8, 8)]:
+        x = _randn((R, Cc), dev, 1.0, R)
+        y = torch.full((Cc, R), 3.0, device=dev, dtype=BF)
+        hip.transpose(x, y)
+        assert torch.equal(y, x.t().contiguous()), (R, Cc)

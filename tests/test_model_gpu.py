@@ -150,6 +150,27 @@ def test_paired_fusion_is_equivalent(models):
     assert _relerr(res[True][1], res[False][1]) < 1e-2
 
 
+def test_transposed_weight_dgrad_matches(models):
+    """dgrad through the resident W^T copies (NT path) == dgrad through W (NN path)."""
+    from multimodal_unlearning_amd.trainer import MMTrainerForgetting
+
+    cfg, P, student, _ = models
+    inputs = make_forget_batch(cfg, 2, 40, seed=9, n_question=7)
+    tr = MMTrainerForgetting(model=student, forget_loss="grad_diff_forget_ce_retain_ce", teacher_model=None,
+                             loss_beta=1.0, l1_lambda=0, l0_lambda=0, l_norm_from="zero")
+    res = []
+    for use_t in (False, True):
+        if use_t:
+            student.enable_transposed_weights()
+        student.ensure_grad().zero_()
+        tr.compute_loss(student, inputs).backward()
+        res.append(student.ensure_grad().clone())
+    student.wT.clear()
+    student._wT_flat = None
+    # same products, same fp32 accumulation; only the k-summation order inside a tile may differ
+    assert _relerr(res[1], res[0]) < 2e-3, _relerr(res[1], res[0])
+
+
 def test_engine_steps_reduce_retain_loss(models, dev):
     from multimodal_unlearning_amd.engine import ForgetEngine
     from multimodal_unlearning_amd.llava import LlavaHIP
