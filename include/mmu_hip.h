@@ -30,6 +30,8 @@ int mmu_gemm_bf16(int layout, const void* A, const void* B, void* C, const void*
 /* Tile configuration override (A/B tests, tuning): 0 = heuristic, 128 = 128x128x64 4-wave kernel,
  * 256 = 256x256x64 8-wave 8-phase kernel.  Process-wide. */
 int mmu_gemm_set_tile(int tile);
+/* Tile rasterisation of the 256x256 kernel (tuning): GROUP_M tile rows swept column by column; 0 = default. */
+int mmu_gemm_set_group_m(int group_m);
 
 /* ---- Attention (replaces the flash-attn wheel: mm/forget.py:86,98,106 attn_implementation=
  * "flash_attention_2"; SURVEY §8a K3 (CLIP, non-causal, head_dim 64) and K10 (Llama, causal, 128)) ----

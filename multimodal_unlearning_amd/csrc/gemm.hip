@@ -23,6 +23,8 @@
 // lane ends up with 4 consecutive n of one output row -> 8-byte bf16x4 stores.
 #include "common.h"
 
+static int g_force_tile = 0;  // mmu_gemm_set_tile
+static int g_group_m = 0;     // mmu_gemm_set_group_m
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -39,6 +41,7 @@ struct GemmArgs {
     int act;         // 0 none, 1 gelu(erf), 2 quick_gelu
     int accumulate;  // C = bf16(float(C) + acc) (grad accumulation)
     int tiles_m, tiles_n;
+    int group_m;  // tile rasterisation: tiles of GROUP_M consecutive tile rows are swept column by column
 };
 
 __device__ __forceinline__ int swzT(int k) { return ((k & 3) << 1) | (((k >> 3) & 1) << 3); }
@@ -309,7 +312,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
         const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = pid & 7, loc = pid >> 3;
         pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
-    constexpr int GROUP_M = 4;
+    const int GROUP_M = p.group_m;
     const int per_group = GROUP_M * p.tiles_n;
     const int gid = pid / per_group;
     const int first_m = gid * GROUP_M;
@@ -478,6 +481,7 @@ int launch_epi(GemmArgs a, hipStream_t stream) {
     }
     a.tiles_m = (a.M + 255) / 256;
     a.tiles_n = (a.N + 255) / 256;
+    a.group_m = g_group_m > 0 ? g_group_m : 4;
     hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(512), LDS_BYTES, stream, a);
     MMU_CHECK_LAUNCH();
     return 0;
@@ -494,7 +498,6 @@ int launch(const GemmArgs& a, hipStream_t stream) {
 
 }  // namespace
 
-static int g_force_tile = 0;
 
 // 256^2 tiles (8-phase kernel) when the grid fills the 256 CUs reasonably; the 128^2 kernel (2 blocks/CU)
 // otherwise.  Wave quantisation: cost ~ rounds * work per CU per round / rate; a 256^2 tile is 4 units at a
@@ -549,5 +552,12 @@ extern "C" int mmu_gemm_bf16(int layout, const void* A, const void* B, void* C, 
 extern "C" int mmu_gemm_set_tile(int tile) {
     if (tile != 0 && tile != 128 && tile != 256) return -1;
     g_force_tile = tile;
+    return 0;
+}
+
+// Rasterisation override for the 256^2 kernel (tuning): 0 = default.
+extern "C" int mmu_gemm_set_group_m(int group_m) {
+    if (group_m < 0 || group_m > 64) return -1;
+    g_group_m = group_m;
     return 0;
 }

@@ -22,6 +22,7 @@ SIGNATURES = {
     "mmu_abi_version": [],
     "mmu_gemm_bf16": [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "mmu_gemm_set_tile": [_i],
+    "mmu_gemm_set_group_m": [_i],
     "mmu_attn_fwd": [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp],
     "mmu_attn_bwd": [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i,
                      _vp],
@@ -125,6 +126,10 @@ def gemm(layout: int, A, B, out, *, bias=None, resid=None, act=0, accumulate=Fal
                               _stream())
     _check(rc, "mmu_gemm_bf16")
     return out
+
+
+def gemm_set_group_m(g: int):
+    _check(load().mmu_gemm_set_group_m(int(g)), "mmu_gemm_set_group_m")
 
 
 def gemm_set_tile(tile: int):

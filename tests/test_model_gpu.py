@@ -171,6 +171,25 @@ def test_transposed_weight_dgrad_matches(models):
     assert _relerr(res[1], res[0]) < 2e-3, _relerr(res[1], res[0])
 
 
+def test_transposed_wgrad_matches(models):
+    """wgrad via [transpose, transpose, NT GEMM] == wgrad via the TN GEMM."""
+    from multimodal_unlearning_amd.trainer import MMTrainerForgetting
+
+    cfg, P, student, _ = models
+    inputs = make_forget_batch(cfg, 2, 40, seed=11, n_question=7)  # fused batch: M = 160 rows
+    tr = MMTrainerForgetting(model=student, forget_loss="grad_diff_forget_ce_retain_ce", teacher_model=None,
+                             loss_beta=1.0, l1_lambda=0, l0_lambda=0, l_norm_from="zero")
+    res = []
+    old = student.transposed_wgrad_min_m
+    for min_m in (1 << 30, 0):
+        student.transposed_wgrad_min_m = min_m
+        student.ensure_grad().zero_()
+        tr.compute_loss(student, inputs).backward()
+        res.append(student.ensure_grad().clone())
+    student.transposed_wgrad_min_m = old
+    assert _relerr(res[1], res[0]) < 2e-3, _relerr(res[1], res[0])
+
+
 def test_engine_steps_reduce_retain_loss(models, dev):
     from multimodal_unlearning_amd.engine import ForgetEngine
     from multimodal_unlearning_amd.llava import LlavaHIP
