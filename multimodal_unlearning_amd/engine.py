@@ -45,13 +45,14 @@ def shard_indices(n: int, rank: int, world: int) -> List[int]:
 class GradBucketReducer:
     """Asynchronous SUM all-reduce of [lo,hi) ranges of one flat gradient tensor.  Works on CPU (gloo) and GPU."""
 
-    def __init__(self, flat_grad: torch.Tensor, group=None, max_bucket_elems: int = 1 << 28):
+    def __init__(self, flat_grad: torch.Tensor, group=None, max_bucket_elems: int = 1 << 28, force: bool = False):
         self.flat = flat_grad
         self.group = group
         self.max_bucket = max_bucket_elems
         self.works = []
         self.reduced_elems = 0
-        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        # force=True runs the collectives even on a 1-rank group (exercises the RCCL path on a single GPU)
+        self.enabled = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force)
 
     def reduce_range(self, lo: int, hi: int):
         if not self.enabled:
@@ -82,7 +83,7 @@ class ForgetEngine:
     """engine.step(micro_batches) = GA x (compute_loss -> backward) -> all-reduce -> clip -> AdamW -> zero grads."""
 
     def __init__(self, model, trainer, cfg: ForgetConfig, total_steps: int = 1000, warmup_steps: int = 0,
-                 group=None, transposed_weights: bool = True):
+                 group=None, transposed_weights: bool = True, force_collectives: bool = False):
         from . import hip  # HIP optimiser kernels; fails loudly when the library is missing
 
         self.hip = hip
@@ -97,7 +98,7 @@ class ForgetEngine:
         self.v = torch.zeros(n, device=dev, dtype=torch.float32)
         self.sumsq = torch.zeros(1, device=dev, dtype=torch.float32)
         self.opt_step = 0
-        self.reducer = GradBucketReducer(self.grad, group)
+        self.reducer = GradBucketReducer(self.grad, group, force=force_collectives)
         if transposed_weights:
             model.enable_transposed_weights()
 

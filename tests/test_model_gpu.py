@@ -205,3 +205,40 @@ def test_engine_steps_reduce_retain_loss(models, dev):
     assert all(np.isfinite(losses)), losses
     assert losses[-1] < losses[0] - 0.5, losses
     assert model.ensure_grad().abs().max().item() == 0  # fused zeroing after the optimiser step
+
+
+def test_engine_rccl_path_single_rank(models, dev):
+    """The DP code path (bucketed async all-reduce launched from the backward sweep, RCCL via backend "nccl")
+    on a 1-rank process group: results must equal the collective-free step."""
+    import torch.distributed as dist
+
+    from multimodal_unlearning_amd.engine import ForgetEngine
+    from multimodal_unlearning_amd.llava import LlavaHIP
+    from multimodal_unlearning_amd.trainer import MMTrainerForgetting
+
+    cfg, P, _, _ = models
+    import os
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        created = True
+    try:
+        outs = []
+        for force in (False, True):
+            model = LlavaHIP(cfg, P, device=dev)
+            tr = MMTrainerForgetting(model=model, forget_loss="grad_diff_forget_ce_retain_ce", teacher_model=None,
+                                     loss_beta=1.0, l1_lambda=0, l0_lambda=0, l_norm_from="zero")
+            eng = ForgetEngine(model, tr, ForgetConfig(lr=1e-3), total_steps=10, warmup_steps=1, force_collectives=force)
+            mbs = [make_forget_batch(cfg, 2, 32, seed=s, n_question=5) for s in (1, 2)]
+            for _ in range(2):
+                st = eng.step(mbs, sync_loss=True)
+            assert eng.reducer.enabled == force
+            outs.append((st.loss, model.train_flat.detach().clone()))
+        assert abs(outs[0][0] - outs[1][0]) < 1e-5
+        # not bit-equal run to run: the embedding backward sums with fp32 atomics (arrival order varies)
+        assert _relerr(outs[1][1], outs[0][1]) < 1e-4
+    finally:
+        if created:
+            dist.destroy_process_group()
