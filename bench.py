@@ -112,7 +112,13 @@ def cpu_baseline(cfg, S, budget_layers=1, clip_layers=2):
     from oracle.forget_losses_ref import compute_loss_ref
     from oracle.llava_ref import llava_forward
 
-    torch.set_num_threads(os.cpu_count() or 1)
+    # the GPU box gives each GPU a 16-core share of the host (256 hardware threads visible): using more
+    # oversubscribes and is 10x slower
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(avail, 16)))
     cores = torch.get_num_threads()
 
     def build(nl, ncl):
