@@ -34,11 +34,11 @@ __device__ __forceinline__ int swz(int r) {
 
 // Stage R rows x D bf16 of a row-major matrix (row stride ld elements) into a swizzled LDS tile.
 // Rows >= row_limit read the zero page.
-template <int D, int KIND, int R>
+template <int D, int KIND, int R, int NW = 4>
 __device__ __forceinline__ void stage_rows(char* tile, const bf16* __restrict__ g, int ld, int row0, int row_limit,
                                            int wave, int lane) {
-    constexpr int ROWB = D * 2, RPI = 1024 / ROWB, CPR = ROWB / 16, NI = R / RPI, PW = NI / 4;
-    static_assert(PW >= 1, "tile too small for 4 waves");
+    constexpr int ROWB = D * 2, RPI = 1024 / ROWB, CPR = ROWB / 16, NI = R / RPI, PW = NI / NW;
+    static_assert(PW >= 1 && PW * NW == NI, "tile does not split evenly over the waves");
     const bf16* zero = reinterpret_cast<const bf16*>(mmu_zero16);
 #pragma unroll
     for (int i = 0; i < PW; ++i) {
@@ -71,6 +71,34 @@ __device__ __forceinline__ bf16x8 tr_frag(const MMU_LDS char* tile, int rbase, i
     const MMU_LDS char* a2 = tile + r2 * (D * 2) + ((ch ^ swz<D, KIND>(r2)) << 4) + sub;
     const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((MMU_LDS bf16x4*)a1);
     const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((MMU_LDS bf16x4*)a2);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+
+// Per-lane LDS byte offsets of the 32x32x16 fragments, relative to a tile address whose fragment starts at a row
+// that is a multiple of 32 (row / transposed reads then only add compile-time constants).
+template <int D, int KIND>
+struct FragOffsets {
+    int row[D / 16];               // row fragment of k-step ks: row (lane&31), 16-B chunk 2ks + (lane>>5)
+    int tr1[D / 32], tr2[D / 32];  // transposed fragment, 32-column block dt, k-step 0 (k-step 1: + 16 rows)
+    __device__ __forceinline__ void init(int lane) {
+        const int hl = lane >> 5, r = lane & 31;
+#pragma unroll
+        for (int ks = 0; ks < D / 16; ++ks) row[ks] = r * (D * 2) + (((2 * ks + hl) ^ swz<D, KIND>(r)) << 4);
+        const int g = lane >> 4, gb = g & 1, h = g >> 1, i = lane & 15, q = i >> 2, pp = i & 3;
+        const int r1 = 4 * h + q, r2 = r1 + 8, sub = (pp & 1) << 3;
+#pragma unroll
+        for (int dt = 0; dt < D / 32; ++dt) {
+            const int ch = 4 * dt + 2 * gb + (pp >> 1);
+            tr1[dt] = r1 * (D * 2) + ((ch ^ swz<D, KIND>(r1)) << 4) + sub;
+            tr2[dt] = r2 * (D * 2) + ((ch ^ swz<D, KIND>(r2)) << 4) + sub;
+        }
+    }
+};
+
+__device__ __forceinline__ bf16x8 tr_load(const MMU_LDS char* p1, const MMU_LDS char* p2) {
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((MMU_LDS bf16x4*)p1);
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((MMU_LDS bf16x4*)p2);
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
@@ -133,6 +161,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qsrc + 16 * ks);
     }
+    FragOffsets<D, KIND_ROW> fo_k;
+    fo_k.init(lane);
+    FragOffsets<D, KIND_TR> fo_v;
+    fo_v.init(lane);
     f32x16 o[NDT];
 #pragma unroll
     for (int i = 0; i < NDT; ++i)
@@ -171,11 +203,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
             for (int st = 0; st < 2; ++st) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) s[st][r] = 0.f;
+                bf16x8 kf[NKS];
 #pragma unroll
-                for (int ks = 0; ks < NKS; ++ks) {
-                    const bf16x8 kf = row_frag<D, KIND_ROW>(kt, st * 32, ks, lane);
-                    s[st] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[st], 0, 0, 0);
-                }
+                for (int ks = 0; ks < NKS; ++ks)
+                    kf[ks] = *(const MMU_LDS bf16x8*)(kt + st * 32 * (D * 2) + fo_k.row[ks]);
+                __builtin_amdgcn_sched_barrier(0);  // the whole fragment batch is in flight before the first MFMA waits
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) s[st] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], s[st], 0, 0, 0);
             }
             // scale (log2 domain), key bias, causal mask
             const bool diag = CAUSAL && (kb * 64 + 63 > q0);
@@ -220,11 +254,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
                 for (int sk = 0; sk < 2; ++sk) {
                     const bf16x8 pf = pack8(s[st], sk);
+                    bf16x8 vf[NDT];
 #pragma unroll
-                    for (int dt = 0; dt < NDT; ++dt) {
-                        const bf16x8 vf = tr_frag<D, KIND_TR>(vt, st * 32, sk, dt * 32, lane);
-                        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
-                    }
+                    for (int dt = 0; dt < NDT; ++dt)
+                        vf[dt] = tr_load(vt + (st * 32 + sk * 16) * (D * 2) + fo_v.tr1[dt],
+                                         vt + (st * 32 + sk * 16) * (D * 2) + fo_v.tr2[dt]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int dt = 0; dt < NDT; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt], pf, o[dt], 0, 0, 0);
                 }
         }
     }
@@ -246,28 +283,31 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     }
 }
 
-// delta[b][h][s] = sum_d dO[b,s,h,d] * O[b,s,h,d]   (one wave per (row, head))
+// delta[b][h][s] = sum_d dO[b,s,h,d] * O[b,s,h,d]: D/8 lanes per (row, head), 16-B loads, shuffle reduce
 template <int D>
 __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict__ o, int ldo,
                                                          const bf16* __restrict__ dout, int lddo,
                                                          float* __restrict__ delta, int B, int S, int H) {
-    const int lane = threadIdx.x & 63;
-    const size_t idx = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // over B*S*H
+    constexpr int LPG = D / 8;  // lanes per (row, head) group
+    const size_t gid = ((size_t)blockIdx.x * 256 + threadIdx.x) / LPG;
+    const int sub = threadIdx.x % LPG;
     const size_t total = (size_t)B * S * H;
-    if (idx >= total) return;
-    const int h = (int)(idx % H);
-    const size_t row = idx / H;
-    constexpr int PER = D / 64;  // elements per lane (2 or 1)
     float acc = 0.f;
+    size_t row = 0;
+    int h = 0;
+    if (gid < total) {
+        h = (int)(gid % H);
+        row = gid / H;
+        const bf16x8 ov = *reinterpret_cast<const bf16x8*>(o + row * ldo + h * D + sub * 8);
+        const bf16x8 dv = *reinterpret_cast<const bf16x8*>(dout + row * lddo + h * D + sub * 8);
 #pragma unroll
-    for (int j = 0; j < PER; ++j) {
-        const int d = lane * PER + j;
-        acc += bf2f(o[row * ldo + h * D + d]) * bf2f(dout[row * lddo + h * D + d]);
+        for (int j = 0; j < 8; ++j) acc += bf2f(ov[j]) * bf2f(dv[j]);
     }
-    acc = wave_sum(acc);
-    if (lane == 0) {
-        const int b = (int)(row / S), s = (int)(row % S);
-        delta[((size_t)b * H + h) * S + s] = acc;
+#pragma unroll
+    for (int off = LPG / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (gid < total && sub == 0) {
+        const int b = (int)(row / S), sq = (int)(row % S);
+        delta[((size_t)b * H + h) * S + sq] = acc;
     }
 }
 
@@ -310,6 +350,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     const size_t sidx = ((size_t)b * a.H + hh) * S + (qvalid ? qrow : S - 1);
     const float lse2 = qvalid ? a.lse[sidx] * LOG2E : INFINITY;
     const float dlt = a.delta[sidx];
+    FragOffsets<D, KIND_ROW> fo;
+    fo.init(lane);
     f32x16 acc[NDT];
 #pragma unroll
     for (int i = 0; i < NDT; ++i)
@@ -348,15 +390,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
                 f32x16 s, dp;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+                {
+                    bf16x8 kf[NKS], vf[NKS];
 #pragma unroll
-                for (int ks = 0; ks < NKS; ++ks) {
-                    const bf16x8 kf = row_frag<D, KIND_ROW>(kt, st * 32, ks, lane);
-                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
-                }
+                    for (int ks = 0; ks < NKS; ++ks) {
+                        kf[ks] = *(const MMU_LDS bf16x8*)(kt + st * 32 * (D * 2) + fo.row[ks]);
+                        vf[ks] = *(const MMU_LDS bf16x8*)(vt + st * 32 * (D * 2) + fo.row[ks]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int ks = 0; ks < NKS; ++ks) {
-                    const bf16x8 vf = row_frag<D, KIND_ROW>(vt, st * 32, ks, lane);
-                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], dp, 0, 0, 0);
+                    for (int ks = 0; ks < NKS; ++ks) {
+                        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], s, 0, 0, 0);
+                        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[ks], dof[ks], dp, 0, 0, 0);
+                    }
                 }
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -373,11 +419,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
 #pragma unroll
                 for (int sk = 0; sk < 2; ++sk) {
                     const bf16x8 dsf = pack8(s, sk);
+                    bf16x8 ktf[NDT];
 #pragma unroll
-                    for (int dt = 0; dt < NDT; ++dt) {
-                        const bf16x8 ktf = tr_frag<D, KIND_ROW>(kt, st * 32, sk, dt * 32, lane);
-                        acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf, dsf, acc[dt], 0, 0, 0);
-                    }
+                    for (int dt = 0; dt < NDT; ++dt)
+                        ktf[dt] = tr_load(kt + (st * 32 + sk * 16) * (D * 2) + fo.tr1[dt],
+                                          kt + (st * 32 + sk * 16) * (D * 2) + fo.tr2[dt]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int dt = 0; dt < NDT; ++dt)
+                        acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[dt], dsf, acc[dt], 0, 0, 0);
                 }
             }
         }
@@ -397,18 +447,26 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// dK / dV. grid (ceil(S/128), H, B); wave w owns keys kvb*128 + 32w .. +31 ("key on the lane") and
-// keeps K, V fragments plus dK^T, dV^T accumulators in registers while the workgroup sweeps 32-row
-// query tiles (Q and dO tiles in LDS, read by rows for S / dP and transposed for dK^T / dV^T).
-// LDS: 2 x (Q tile 32xD | dO tile 32xD) + 2 x (32 lse2 | 32 delta).
+// dK / dV. grid (ceil(S/128), H, B), 512 threads = 8 waves.  Wave w: key group kw = w&3 (keys kvb*128 + 32kw ..
+// +31, "key on the lane") and query half qh = w>>2: every iteration the block stages TWO 32-row query tiles and
+// waves 0-3 take the first, waves 4-7 the second, so each SIMD holds two waves that hide each other's LDS
+// latency.  A wave keeps dK^T, dV^T partial accumulators (128 registers) for its keys; the two partials of a key
+// group are summed through LDS once, after the sweep.  The block's K and V tiles (128 keys) stay in LDS for
+// the whole sweep (B operands of S = Q K^T and dP = dO V^T); Q / dO tiles are double-buffered by LDS-DMA and
+// read by rows (S, dP) and transposed (dK^T += Q^T dS, dV^T += dO^T P); lse / delta rows arrive by 4-byte
+// LDS-DMA (no register round trip inside the loop).  Per-lane LDS offsets of every fragment are computed once.
+// LDS: K 128xD | V 128xD | 2 x (Q 64xD | dO 64xD) | 2 x (64 lse | 64 delta)  = 129 KiB.
 // ------------------------------------------------------------------------------------------------
 template <int D, bool CAUSAL>
-__global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(AttnArgs a) {
+__global__ __launch_bounds__(512, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
+    static_assert(D == 128, "backward is built for head_dim 128");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int TB = 32 * D * 2;
+    constexpr int KVB = 128 * D * 2;  // K (or V) tile bytes
+    constexpr int TB = 64 * D * 2;    // Q (or dO) pair-tile bytes (2 x 32 rows)
     constexpr int NKS = D / 16, NDT = D / 32;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int kw = wave & 3, qh = wave >> 2;
     const int hl = lane >> 5;
     const int kvb = blockIdx.x, hh = blockIdx.y, b = blockIdx.z;
     const int S = a.S;
@@ -419,22 +477,33 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(AttnArgs a) {
     const bf16* dop = a.dout + rowbase * a.lddo + hh * D;
     const float* lsep = a.lse + ((size_t)b * a.H + hh) * S;
     const float* dltp = a.delta + ((size_t)b * a.H + hh) * S;
-    float* rowc = reinterpret_cast<float*>(smem + 4 * TB);  // [2][64]: 32 lse2 | 32 delta
+    char* qd_base = smem + 2 * KVB;                                   // [2][Q | dO]
+    float* rowc = reinterpret_cast<float*>(smem + 2 * KVB + 4 * TB);  // [2][lse 64 | delta 64]
 
-    const int key0 = kvb * 128 + wave * 32;
+    const int key0 = kvb * 128 + kw * 32;
     const int key = key0 + (lane & 31);
     const bool kvalid = key < S && (a.kmask == nullptr || a.kmask[rowbase + key] != 0);
-    bf16x8 kf[NKS], vf[NKS];
+
+    // per-lane fragment offsets (bytes, relative to a tile whose fragment starts at row 0)
+    int off_row[NKS];  // row fragment, k-step ks: row (lane&31), chunk 2ks+hl
     {
-        const size_t rr = (size_t)(key < S ? key : S - 1);
-        const bf16* ksrc = kp + rr * a.ld + 8 * hl;
-        const bf16* vsrc = vp + rr * a.ld + 8 * hl;
+        const int r = lane & 31;
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-            kf[ks] = *reinterpret_cast<const bf16x8*>(ksrc + 16 * ks);
-            vf[ks] = *reinterpret_cast<const bf16x8*>(vsrc + 16 * ks);
+        for (int ks = 0; ks < NKS; ++ks) off_row[ks] = r * (D * 2) + (((2 * ks + hl) ^ swz<D, KIND_ROW>(r)) << 4);
+    }
+    int off_tr1[NDT], off_tr2[NDT];  // transposed fragment for k-step 0 (k-step 1: + 16 rows = 16*D*2 bytes)
+    {
+        const int g = lane >> 4, gb = g & 1, h = g >> 1, i = lane & 15, q = i >> 2, pp = i & 3;
+        const int r1 = 4 * h + q, r2 = r1 + 8;
+        const int sub = (pp & 1) << 3;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+            const int ch = 4 * dt + 2 * gb + (pp >> 1);
+            off_tr1[dt] = r1 * (D * 2) + ((ch ^ swz<D, KIND_ROW>(r1)) << 4) + sub;
+            off_tr2[dt] = r2 * (D * 2) + ((ch ^ swz<D, KIND_ROW>(r2)) << 4) + sub;
         }
     }
+
     f32x16 dk[NDT], dv[NDT];
 #pragma unroll
     for (int i = 0; i < NDT; ++i)
@@ -442,56 +511,78 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(AttnArgs a) {
         for (int r = 0; r < 16; ++r) { dk[i][r] = 0.f; dv[i][r] = 0.f; }
     const float c = a.scale * LOG2E;
 
-    const int qt0 = CAUSAL ? (kvb * 128) / 32 : 0;
-    const int qt1 = (S + 31) / 32;
+    // query-tile PAIRS: pair p covers rows 64p .. 64p+63
+    const int pr0 = CAUSAL ? (kvb * 128) / 64 : 0;
+    const int pr1 = (S + 63) / 64;
 
-    auto stage = [&](int qt, int buf) {
-        char* base = smem + buf * 2 * TB;
-        stage_rows<D, KIND_ROW, 32>(base, qp, a.ld, qt * 32, S, wave, lane);
-        stage_rows<D, KIND_ROW, 32>(base + TB, dop, a.lddo, qt * 32, S, wave, lane);
-        if (threadIdx.x < 32) {
-            const int qr = qt * 32 + threadIdx.x;
-            rowc[buf * 64 + threadIdx.x] = qr < S ? lsep[qr] * LOG2E : INFINITY;
-            rowc[buf * 64 + 32 + threadIdx.x] = qr < S ? dltp[qr] : 0.f;
+    auto stage = [&](int pr, int buf) {
+        char* base = qd_base + buf * 2 * TB;
+        stage_rows<D, KIND_ROW, 64, 8>(base, qp, a.ld, pr * 64, S, wave, lane);
+        stage_rows<D, KIND_ROW, 64, 8>(base + TB, dop, a.lddo, pr * 64, S, wave, lane);
+        if (wave < 2) {
+            // wave 0: lse of the 64 rows, wave 1: delta, by 4-byte LDS-DMA (natural-log lse; scaled on use)
+            const int qr = pr * 64 + lane;
+            const float* src = wave == 0 ? (qr < S ? lsep + qr : reinterpret_cast<const float*>(mmu_inf16))
+                                         : (qr < S ? dltp + qr : reinterpret_cast<const float*>(mmu_zero16));
+            glds4(src, rowc + buf * 128 + wave * 64);
         }
     };
 
-    if (qt0 < qt1) stage(qt0, 0);
-    for (int qt = qt0; qt < qt1; ++qt) {
-        const int cur = (qt - qt0) & 1;
+    // block-resident K and V tiles (rows past S read the zero page)
+    stage_rows<D, KIND_ROW, 128, 8>(smem, kp, a.ld, kvb * 128, S, wave, lane);
+    stage_rows<D, KIND_ROW, 128, 8>(smem + KVB, vp, a.ld, kvb * 128, S, wave, lane);
+    if (pr0 < pr1) stage(pr0, 0);
+
+    const MMU_LDS char* ktile = (const MMU_LDS char*)smem + kw * 32 * (D * 2);
+    const MMU_LDS char* vtile = ktile + KVB;
+
+    for (int pr = pr0; pr < pr1; ++pr) {
+        const int cur = (pr - pr0) & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (qt + 1 < qt1) stage(qt + 1, cur ^ 1);
-        const bool active = !CAUSAL || (qt * 32 + 31 >= key0);
+        if (pr + 1 < pr1) stage(pr + 1, cur ^ 1);
+        const int q_first = pr * 64 + qh * 32;  // first query row of this wave's tile
+        const bool active = q_first < S && (!CAUSAL || (q_first + 31 >= key0));
         if (active) {
-            const MMU_LDS char* qtile = (const MMU_LDS char*)smem + cur * 2 * TB;
+            const MMU_LDS char* qtile = (const MMU_LDS char*)qd_base + cur * 2 * TB + qh * 32 * (D * 2);
             const MMU_LDS char* dotile = qtile + TB;
-            const MMU_LDS float* rc = (const MMU_LDS float*)(smem + 4 * TB) + cur * 64;
+            const MMU_LDS float* rc = (const MMU_LDS float*)(smem + 2 * KVB + 4 * TB) + cur * 128 + qh * 32;
             f32x16 s, dp;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-            // S[q][key] = Q K^T ; dP[q][key] = dO V^T   (A = tile rows, B = register fragments)
+            {   // S[q][key] = Q K^T
+                bf16x8 fa[NKS], fb[NKS];
 #pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) {
-                const bf16x8 qa = row_frag<D, KIND_ROW>(qtile, 0, ks, lane);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], s, 0, 0, 0);
-            }
+                for (int ks = 0; ks < NKS; ++ks) {
+                    fa[ks] = *(const MMU_LDS bf16x8*)(qtile + off_row[ks]);
+                    fb[ks] = *(const MMU_LDS bf16x8*)(ktile + off_row[ks]);
+                }
+                __builtin_amdgcn_sched_barrier(0);  // all 16 reads in flight before the first MFMA waits
 #pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) {
-                const bf16x8 da = row_frag<D, KIND_ROW>(dotile, 0, ks, lane);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[ks], dp, 0, 0, 0);
+                for (int ks = 0; ks < NKS; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks], fb[ks], s, 0, 0, 0);
             }
-            const bool diag = CAUSAL && (qt * 32 < key0 + 31);
+            {   // dP[q][key] = dO V^T
+                bf16x8 fa[NKS], fb[NKS];
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) {
+                    fa[ks] = *(const MMU_LDS bf16x8*)(dotile + off_row[ks]);
+                    fb[ks] = *(const MMU_LDS bf16x8*)(vtile + off_row[ks]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks], fb[ks], dp, 0, 0, 0);
+            }
+            const bool diag = CAUSAL && (q_first < key0 + 31);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int ql = 8 * g + 4 * hl;  // local q row of reg 4g
                 const f32x4 l4 = *(const MMU_LDS f32x4*)(rc + ql);
-                const f32x4 d4 = *(const MMU_LDS f32x4*)(rc + 32 + ql);
+                const f32x4 d4 = *(const MMU_LDS f32x4*)(rc + 64 + ql);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    float x = s[4 * g + j] * c - l4[j];
+                    const float x = s[4 * g + j] * c - l4[j] * LOG2E;
                     bool ok = kvalid;
-                    if (diag && (key > qt * 32 + ql + j)) ok = false;
+                    if (diag && (key > q_first + ql + j)) ok = false;
                     const float p = ok ? fast_exp2(x) : 0.f;
                     s[4 * g + j] = p;
                     dp[4 * g + j] = p * (dp[4 * g + j] - d4[j]) * a.scale;
@@ -502,17 +593,44 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(AttnArgs a) {
             for (int sk = 0; sk < 2; ++sk) {
                 const bf16x8 pf = pack8(s, sk);
                 const bf16x8 dsf = pack8(dp, sk);
+                bf16x8 fo[NDT], fq[NDT];
 #pragma unroll
                 for (int dt = 0; dt < NDT; ++dt) {
-                    const bf16x8 dot_ = tr_frag<D, KIND_ROW>(dotile, 0, sk, dt * 32, lane);
-                    dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dot_, pf, dv[dt], 0, 0, 0);
-                    const bf16x8 qt_ = tr_frag<D, KIND_ROW>(qtile, 0, sk, dt * 32, lane);
-                    dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt_, dsf, dk[dt], 0, 0, 0);
+                    const bf16x4 o1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (MMU_LDS bf16x4*)(dotile + off_tr1[dt] + sk * 16 * D * 2));
+                    const bf16x4 o2 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (MMU_LDS bf16x4*)(dotile + off_tr2[dt] + sk * 16 * D * 2));
+                    fo[dt] = __builtin_shufflevector(o1, o2, 0, 1, 2, 3, 4, 5, 6, 7);
+                    const bf16x4 q1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (MMU_LDS bf16x4*)(qtile + off_tr1[dt] + sk * 16 * D * 2));
+                    const bf16x4 q2 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (MMU_LDS bf16x4*)(qtile + off_tr2[dt] + sk * 16 * D * 2));
+                    fq[dt] = __builtin_shufflevector(q1, q2, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) {
+                    dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fo[dt], pf, dv[dt], 0, 0, 0);
+                    dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[dt], dsf, dk[dt], 0, 0, 0);
                 }
             }
         }
     }
-    if (key < S) {
+    // sum the two query-half partials of every key group through LDS: waves 4-7 publish, waves 0-3 add + store.
+    // slab layout [kw][reg 0..127][lane] fp32 -> lane-contiguous, conflict-free; 4 x 32 KiB over the dead tiles.
+    __syncthreads();
+    float* slab = reinterpret_cast<float*>(smem) + kw * (128 * 64);
+    if (qh == 1) {
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                slab[(dt * 16 + r) * 64 + lane] = dk[dt][r];
+                slab[(64 + dt * 16 + r) * 64 + lane] = dv[dt][r];
+            }
+    }
+    __syncthreads();
+    if (qh == 0 && key < S) {
         bf16* dkp = a.dk + (rowbase + key) * a.ldg + hh * D;
         bf16* dvp = a.dv + (rowbase + key) * a.ldg + hh * D;
 #pragma unroll
@@ -522,8 +640,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(AttnArgs a) {
                 bf16x4 t, u;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    t[j] = f2bf(dk[dt][4 * g + j]);
-                    u[j] = f2bf(dv[dt][4 * g + j]);
+                    const int r = 4 * g + j;
+                    t[j] = f2bf(dk[dt][r] + slab[(dt * 16 + r) * 64 + lane]);
+                    u[j] = f2bf(dv[dt][r] + slab[(64 + dt * 16 + r) * 64 + lane]);
                 }
                 *reinterpret_cast<bf16x4*>(dkp + dt * 32 + 8 * g + 4 * hl) = t;
                 *reinterpret_cast<bf16x4*>(dvp + dt * 32 + 8 * g + 4 * hl) = u;
@@ -555,7 +674,7 @@ int launch_fwd(const AttnArgs& a, hipStream_t s) {
 template <int D, bool CAUSAL>
 int launch_bwd(const AttnArgs& a, hipStream_t s) {
     constexpr int LDS_DQ = 4 * 64 * D * 2 + 2 * 64 * 4;
-    constexpr int LDS_KV = 4 * 32 * D * 2 + 2 * 64 * 4;
+    constexpr int LDS_KV = 2 * 128 * D * 2 + 4 * 64 * D * 2 + 2 * 128 * 4;
     static bool cfg = false;
     if (!cfg) {
         int e = set_lds(attn_bwd_dq_kernel<D, CAUSAL>, LDS_DQ);
@@ -564,11 +683,11 @@ int launch_bwd(const AttnArgs& a, hipStream_t s) {
         if (e) return e;
         cfg = true;
     }
-    const size_t nrh = (size_t)a.B * a.S * a.H;
-    hipLaunchKernelGGL((attn_delta_kernel<D>), dim3((unsigned)((nrh + 3) / 4)), dim3(256), 0, s, a.o, a.ldo, a.dout,
+    const size_t nthr = (size_t)a.B * a.S * a.H * (D / 8);
+    hipLaunchKernelGGL((attn_delta_kernel<D>), dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, a.o, a.ldo, a.dout,
                        a.lddo, const_cast<float*>(a.delta), a.B, a.S, a.H);
     MMU_CHECK_LAUNCH();
-    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<D, CAUSAL>), dim3((a.S + 127) / 128, a.H, a.B), dim3(256), LDS_KV, s, a);
+    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<D, CAUSAL>), dim3((a.S + 127) / 128, a.H, a.B), dim3(512), LDS_KV, s, a);
     MMU_CHECK_LAUNCH();
     hipLaunchKernelGGL((attn_bwd_dq_kernel<D, CAUSAL>), dim3((a.S + 127) / 128, a.H, a.B), dim3(256), LDS_DQ, s, a);
     MMU_CHECK_LAUNCH();

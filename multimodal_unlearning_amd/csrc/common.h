@@ -28,6 +28,10 @@ static __device__ __attribute__((aligned(16))) const uint32_t mmu_zero16[4] = {0
 // bf16 <-> f32 through the bit pattern.  A plain `(float)(bf16)x` round trip is NOT used for intermediate
 // roundings: clang keeps bf16 expressions in excess (f32) precision and elides the rounding, which changes
 // results where the reference rounds every bf16 tensor op (measured on gfx950: RoPE off by 1 ulp).
+// +inf words: LDS-DMA source for out-of-range log-sum-exp entries (exp2(x - inf) = 0)
+static __device__ __attribute__((aligned(16))) const uint32_t mmu_inf16[4] = {0x7f800000u, 0x7f800000u, 0x7f800000u,
+                                                                              0x7f800000u};
+
 __device__ __forceinline__ float bf2f(bf16 x) {
     return __uint_as_float(((uint32_t)__builtin_bit_cast(unsigned short, x)) << 16);
 }
@@ -37,6 +41,11 @@ __device__ __forceinline__ float round_bf16(float x) { return bf2f((bf16)x); }
 // async global -> LDS, 16 B per lane; LDS destination = wave-uniform base + lane*16.
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const MMU_GLOBAL void*)gsrc, (MMU_LDS void*)lds_wave_base, 16, 0, 0);
+}
+
+// async global -> LDS, 4 B per lane; LDS destination = wave-uniform base + lane*4.
+__device__ __forceinline__ void glds4(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const MMU_GLOBAL void*)gsrc, (MMU_LDS void*)lds_wave_base, 4, 0, 0);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

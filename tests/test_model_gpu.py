@@ -237,8 +237,9 @@ def test_engine_rccl_path_single_rank(models, dev):
             assert eng.reducer.enabled == force
             outs.append((st.loss, model.train_flat.detach().clone()))
         assert abs(outs[0][0] - outs[1][0]) < 1e-5
-        # not bit-equal run to run: the embedding backward sums with fp32 atomics (arrival order varies)
-        assert _relerr(outs[1][1], outs[0][1]) < 1e-4
+        # not bit-equal run to run: the embedding backward sums with fp32 atomics (arrival order varies) and AdamW
+        # turns a last-bit gradient difference into a +-lr step on near-zero-gradient elements
+        assert _relerr(outs[1][1], outs[0][1]) < 2e-3
     finally:
         if created:
             dist.destroy_process_group()
