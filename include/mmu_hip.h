@@ -91,7 +91,8 @@ int mmu_ce_bwd(const void* logits, int ldv, const long long* labels, const float
                int shift, void* stream);
 int mmu_seg_reduce(const float* vals, const long long* labels, int seg_rows, int M, int V, int S, int shift,
                    float* out_sum, float* out_cnt, void* stream);
-/* mode 0: KL(input=student,target=teacher) 1: KL(input=teacher,target=student) 2: NPO 3: entropy sum p log p.
+/* mode 0: KL(input=student,target=teacher) 1: KL(input=teacher,target=student) 2: NPO 3: entropy sum p log p
+ * 4: nlp-trainer NPO form sum log(1 + (lp_s - lp_t)^beta) (nlp/dataloader.py:396-401).
  * stats [M][4] = {lse_s, lse_t, row value, aux}. */
 int mmu_rowloss_fwd(int mode, const void* slog, const void* tlog, int ldv, float beta, float* stats, int M, int V,
                     void* stream);

@@ -162,6 +162,8 @@ __global__ __launch_bounds__(256) void seg_reduce_kernel(const float* __restrict
 //   mode 1  KL(input=teacher, target=student): sum_v p_s (lp_s - lp_t)     (scrub, llmu)
 //   mode 2  NPO: sum_v log(1 + (p_s / (p_t + 1e-8))^beta); aux = sum_v beta r^beta / (1 + r^beta)
 //   mode 3  entropy term: sum_v p_s lp_s   (teacher unused)
+//   mode 4  nlp NPO form (nlp/dataloader.py:396-401): sum_v log(1 + (lp_s - lp_t)^beta); aux = sum_v dterm/dr
+//           (torch.pow semantics: NaN for a negative base with a non-integer exponent, as in the reference)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void rowloss_fwd_kernel(int mode, const bf16* __restrict__ slog,
                                                           const bf16* __restrict__ tlog, int ldv, float beta,
@@ -190,6 +192,11 @@ __global__ __launch_bounds__(256) void rowloss_fwd_kernel(int mode, const bf16* 
                 const float rb = __expf(beta * (lps - __logf(__expf(lpt) + 1e-8f)));  // r^beta
                 acc += log1pf(rb);
                 aux += beta * rb / (1.f + rb);
+            } else if (mode == 4) {
+                const float r = lps - lpt;
+                const float rb = powf(r, beta);
+                acc += logf(1.f + rb);
+                aux += beta * powf(r, beta - 1.f) / (1.f + rb);
             } else {
                 acc += __expf(lps) * lps;
             }
@@ -238,6 +245,9 @@ __global__ __launch_bounds__(256) void rowloss_bwd_kernel(int mode, const bf16* 
             } else if (mode == 2) {
                 const float rb = __expf(beta * (lps - __logf(__expf(lpt) + 1e-8f)));
                 g = beta * rb / (1.f + rb) - ps * aux;
+            } else if (mode == 4) {
+                const float r = lps - lpt;
+                g = beta * powf(r, beta - 1.f) / (1.f + powf(r, beta)) - ps * aux;
             } else {
                 g = ps * (lps - val);
             }
@@ -280,7 +290,7 @@ extern "C" int mmu_seg_reduce(const float* vals, const long long* labels, int se
 
 extern "C" int mmu_rowloss_fwd(int mode, const void* slog, const void* tlog, int ldv, float beta, float* stats, int M,
                                int V, void* stream) {
-    if (M <= 0 || (V & 7) || (ldv & 7) || mode < 0 || mode > 3 || (mode != 3 && !tlog)) return -1;
+    if (M <= 0 || (V & 7) || (ldv & 7) || mode < 0 || mode > 4 || (mode != 3 && !tlog)) return -1;
     hipLaunchKernelGGL(rowloss_fwd_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, mode, (const bf16*)slog,
                        (const bf16*)tlog, ldv, beta, stats, M, V);
     MMU_CHECK_LAUNCH();
@@ -289,7 +299,7 @@ extern "C" int mmu_rowloss_fwd(int mode, const void* slog, const void* tlog, int
 
 extern "C" int mmu_rowloss_bwd(int mode, const void* slog, const void* tlog, int ldv, float beta, const float* stats,
                                const float* coef, void* dlogits, int ldd, int M, int V, void* stream) {
-    if (M <= 0 || (V & 7) || (ldv & 7) || (ldd & 7) || mode < 0 || mode > 3 || (mode != 3 && !tlog)) return -1;
+    if (M <= 0 || (V & 7) || (ldv & 7) || (ldd & 7) || mode < 0 || mode > 4 || (mode != 3 && !tlog)) return -1;
     hipLaunchKernelGGL(rowloss_bwd_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, mode, (const bf16*)slog,
                        (const bf16*)tlog, ldv, beta, stats, coef, (bf16*)dlogits, ldd, M, V);
     MMU_CHECK_LAUNCH();

@@ -308,7 +308,7 @@ def seg_reduce(vals, labels, seg_rows, M, V, S, shift, out_sum, out_cnt):
                                  _stream()), "mmu_seg_reduce")
 
 
-KL_STUDENT_INPUT, KL_TEACHER_INPUT, NPO, ENTROPY = 0, 1, 2, 3
+KL_STUDENT_INPUT, KL_TEACHER_INPUT, NPO, ENTROPY, NPO_NLP = 0, 1, 2, 3, 4
 
 
 def rowloss_fwd(mode, slog, tlog, beta, stats):

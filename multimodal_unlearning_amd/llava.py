@@ -367,14 +367,37 @@ class LlavaHIP(nn.Module):
         hip.gemm(hip.NT, p1a, w["projector.linear_2.weight"], img, bias=w["projector.linear_2.bias"])
         return img, (feats, p1, p1a)
 
-    def _forward_impl(self, ids, kmask, pix, pos, save: bool):
+    def hidden_states(self, layer: int, input_ids=None, attention_mask=None, pixel_values=None, position_ids=None,
+                      **_unused):
+        """Output of decoder layer `layer` ([B,S,d], attached to autograd) — what the reference captures with a
+        forward hook on `language_model.model.layers[layer]` (mm/trainer_utils.py:24-45, mm/trainer.py:302-326).
+        The sweep stops at that layer: the layers above cannot influence the captured activation or its gradient."""
+        dev = self.device
+        kmask = None
+        if attention_mask is not None:
+            if attention_mask.device.type != "cpu" or not bool(attention_mask.all()):
+                kmask = attention_mask.to(dev, dtype=torch.int32).contiguous()
+        ids = input_ids.to(dev, dtype=torch.int64).contiguous()
+        B, S = ids.shape
+        pos = (torch.arange(S, device=dev, dtype=torch.int32).repeat(B) if position_ids is None
+               else position_ids.to(dev, dtype=torch.int32).reshape(-1).contiguous())
+        pix = None
+        if pixel_values is not None and pixel_values.numel() > 0:
+            pix = pixel_values.to(dev, dtype=torch.float32).contiguous()
+        if torch.is_grad_enabled() and self.train_flat.requires_grad:
+            return _LlavaFn.apply(self.train_flat, self, ids, kmask, pix, pos, layer)
+        with torch.no_grad():
+            out, _ = self._forward_impl(ids, kmask, pix, pos, save=False, stop_layer=layer)
+        return out
+
+    def _forward_impl(self, ids, kmask, pix, pos, save: bool, stop_layer: Optional[int] = None):
         cfg, t, w = self.cfg, self.cfg.text, self.w
         dev = self.device
         B, S = ids.shape
         M = B * S
         dt, I, H, D = t.hidden_size, t.intermediate_size, t.num_heads, t.head_dim
         assert S <= t.max_position
-        saved = {"B": B, "S": S, "ids": ids, "kmask": kmask, "pos": pos, "layers": []}
+        saved = {"B": B, "S": S, "ids": ids, "kmask": kmask, "pos": pos, "layers": [], "stop_layer": stop_layer}
         img = None
         slot = None
         if pix is not None:
@@ -414,6 +437,8 @@ class LlavaHIP(nn.Module):
             h = hn
             if self.capture_layer is not None and i == self.capture_layer:
                 self._last_capture = h.view(B, S, dt)
+            if stop_layer is not None and i == stop_layer:
+                return h.view(B, S, dt), saved
         rstdf = torch.empty(M, device=dev, dtype=torch.float32)
         hip.rmsnorm_fwd(h, w["text.norm.weight"], y, rstdf, t.rms_norm_eps)
         logits = torch.empty(M, t.vocab_size, device=dev, dtype=BF)
@@ -432,26 +457,34 @@ class LlavaHIP(nn.Module):
         M = B * S
         dt, I, H, D, V = t.hidden_size, t.intermediate_size, t.num_heads, t.head_dim, t.vocab_size
         scale = D ** -0.5
-        dlog = dlogits.reshape(M, V)
+        dlog = dlogits.reshape(M, -1)
         if not dlog.is_contiguous():
             dlog = dlog.contiguous()
+        if dlog.dtype != BF:
+            dlog = dlog.to(BF)
         npart = hip.rmsnorm_bwd_nparts(M)
         dw_part = torch.empty(npart * dt, device=dev, dtype=torch.float32)
         y = torch.empty(M, dt, device=dev, dtype=BF)
         hook = self.grad_ready_hook
 
-        h, rstdf = saved["final"]
-        hip.rmsnorm_fwd(h, w["text.norm.weight"], y, None, t.rms_norm_eps)
-        self._wgrad(dlog, y, "lm_head.weight")
+        stop_layer = saved.get("stop_layer")
         dy = torch.empty(M, dt, device=dev, dtype=BF)
-        self._dgrad(dlog, "lm_head.weight", dy)
-        dh = torch.empty(M, dt, device=dev, dtype=BF)
-        hip.rmsnorm_bwd(dy, h, w["text.norm.weight"], rstdf, None, dh, dw_part, g["text.norm.weight"], True)
+        if stop_layer is None:
+            h, rstdf = saved["final"]
+            hip.rmsnorm_fwd(h, w["text.norm.weight"], y, None, t.rms_norm_eps)
+            self._wgrad(dlog, y, "lm_head.weight")
+            self._dgrad(dlog, "lm_head.weight", dy)
+            dh = torch.empty(M, dt, device=dev, dtype=BF)
+            hip.rmsnorm_bwd(dy, h, w["text.norm.weight"], rstdf, None, dh, dw_part, g["text.norm.weight"], True)
+            top = t.num_layers - 1
+        else:
+            dh = dlog.clone()  # gradient of the captured activation; the layers above get no gradient
+            top = stop_layer
         if hook:
-            hook(self._off["text.norm.weight"][1], self.range_of("lm_head.weight")[1])
+            hook(self.layer_grad_range(top)[1], self.range_of("lm_head.weight")[1])
         delta = torch.empty(B, H, S, device=dev, dtype=torch.float32)
         layers = saved["layers"]
-        for i in reversed(range(t.num_layers)):
+        for i in reversed(range(top + 1)):
             p = f"text.layers.{i}."
             hin, rstd1, qkv, a, lse, h2, rstd2, gu = layers[i]
             layers[i] = None
@@ -520,8 +553,8 @@ class _LlavaFn(torch.autograd.Function):
     into the model's flat gradient buffer (train_flat.grad) and returns no tensor for it."""
 
     @staticmethod
-    def forward(ctx, train_flat, model: LlavaHIP, ids, kmask, pix, pos):
-        logits, saved = model._forward_impl(ids, kmask, pix, pos, save=True)
+    def forward(ctx, train_flat, model: LlavaHIP, ids, kmask, pix, pos, stop_layer=None):
+        logits, saved = model._forward_impl(ids, kmask, pix, pos, save=True, stop_layer=stop_layer)
         ctx.model = model
         ctx.saved = saved
         return logits
@@ -531,4 +564,4 @@ class _LlavaFn(torch.autograd.Function):
         model, saved = ctx.model, ctx.saved
         ctx.saved = None
         model._backward_impl(saved, dlogits)
-        return None, None, None, None, None, None
+        return None, None, None, None, None, None, None

@@ -47,6 +47,31 @@ def make_split(cfg: LlavaConfig, batch: int, seq_len: int, seed: int, n_question
     return {k: v.to(device) for k, v in out.items()}
 
 
+def make_text_split(cfg: LlavaConfig, batch: int, seq_len: int, seed: int, n_question: int = 0,
+                    right_pad: Optional[List[int]] = None, device="cpu") -> Dict[str, torch.Tensor]:
+    """Text-only split with the layout of nlp/data_module.py:10-43 (`convert_raw_data_to_model_format`): fixed
+    length, RIGHT padding with the EOS id, attention_mask 0 on the padding, labels = ids with the question span
+    and every padded position but the first set to -100 (the first EOS stays supervised, :33-36)."""
+    rng = np.random.default_rng(seed)
+    V = cfg.text.vocab_size
+    eos = 2
+    hi = min(V - 1, cfg.image_token_index) if cfg.image_token_index >= 3 else V
+    ids = np.full((batch, seq_len), eos, dtype=np.int64)
+    mask = np.zeros((batch, seq_len), dtype=np.int64)
+    labels = np.full((batch, seq_len), -100, dtype=np.int64)
+    for b in range(batch):
+        pad = 0 if right_pad is None else int(right_pad[b])
+        body = seq_len - pad
+        ids[b, 0] = 1
+        ids[b, 1:body] = rng.integers(3, hi, size=body - 1)
+        mask[b, :body] = 1
+        labels[b, n_question:body] = ids[b, n_question:body]
+        if pad > 0:
+            labels[b, body] = eos
+    out = OrderedDict(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask), labels=torch.from_numpy(labels))
+    return {k: v.to(device) for k, v in out.items()}
+
+
 def make_forget_batch(cfg: LlavaConfig, batch: int, seq_len: int, seed: int, n_question: int,
                       splits=("forget", "retain"), device="cpu") -> Dict[str, Dict[str, torch.Tensor]]:
     """Nested dict exactly as MMTrainerForgetting.compute_loss consumes it (mm/trainer.py:170-177)."""

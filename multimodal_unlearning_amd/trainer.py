@@ -45,6 +45,7 @@ class MMTrainerForgetting:
         self.data_collator = kwargs.pop("data_collator", None)
         self.tokenizer = kwargs.pop("tokenizer", None)
         self.fuse_pairs = bool(self.loss_args.get("fuse_pairs", True))
+        self.control_vec = None
         self.is_deepspeed_enabled = False
         if tu.loss_needs_teacher(self.loss_type) and self.teacher_model is None:
             raise ValueError(f"forget_loss={self.loss_type} evaluates a frozen teacher: pass teacher_model")
@@ -63,8 +64,12 @@ class MMTrainerForgetting:
 
     @staticmethod
     def _can_fuse(a, b):
-        return (a is not None and b is not None and a["input_ids"].shape == b["input_ids"].shape
-                and a["pixel_values"].shape[1:] == b["pixel_values"].shape[1:])
+        if a is None or b is None or a["input_ids"].shape != b["input_ids"].shape:
+            return False
+        pa, pb = a.get("pixel_values"), b.get("pixel_values")
+        if (pa is None) != (pb is None):
+            return False
+        return pa is None or pa.shape[1:] == pb.shape[1:]
 
     def _paired_ce(self, model, a, b):
         """One forward over cat(a, b); returns (ce_a, ce_b, outputs)."""
@@ -76,10 +81,11 @@ class MMTrainerForgetting:
 
     def compute_loss(self, model, inputs, return_outputs=False, *args, **kwargs):
         dev = next(model.parameters()).device
-        retain_inputs = self.to_device(dev, inputs["retain"]) if "retain" in inputs else None
-        idk_inputs = self.to_device(dev, inputs["idk"]) if "idk" in inputs else None
-        forget_inputs = self.to_device(dev, inputs["forget"]) if "forget" in inputs else None
-        random_inputs = self.to_device(dev, inputs["random"]) if "random" in inputs else None
+        td = MMTrainerForgetting.to_device  # (the text-trainer subclass overrides to_device for tuples)
+        retain_inputs = td(dev, inputs["retain"]) if "retain" in inputs else None
+        idk_inputs = td(dev, inputs["idk"]) if "idk" in inputs else None
+        forget_inputs = td(dev, inputs["forget"]) if "forget" in inputs else None
+        random_inputs = td(dev, inputs["random"]) if "random" in inputs else None
         lt, beta = self.loss_type, self.loss_beta
         outputs = None
 
@@ -196,12 +202,28 @@ class MMTrainerForgetting:
                     + self.loss_args["normal_weight"] * normal_loss)
 
         elif lt == "rmu":
-            raise NotImplementedError("rmu (mm/trainer.py:302-326) is outside BASELINE's loss surface; SURVEY §8f row 4")
+            # mm/trainer.py:302-326: forward hooks on decoder layer 7; MSE towards a cached random control vector
+            # (forget) + MSE to the teacher's activation (retain).  The hidden-state sweep stops at that layer.
+            layer = int(self.loss_args.get("rmu_layer", 7))
+            strip = lambda d: {k: v for k, v in d.items() if k != "labels"}
+            forget_act = model.hidden_states(layer, **strip(forget_inputs)).float()
+            if getattr(self, "control_vec", None) is None:
+                rand_vec = torch.rand(forget_act.shape[0], 1, forget_act.shape[-1], dtype=forget_act.dtype,
+                                      device=forget_act.device)
+                self.control_vec = rand_vec / torch.norm(rand_vec) * 300
+            # NOTE the reference's shapes: input [B,H] vs target [B,1,H] broadcast to [B,B,H] (kept on purpose)
+            forget_loss = torch.nn.functional.mse_loss(forget_act.mean(dim=1), self.control_vec.to(forget_act.device)) * beta
+            retain_act = model.hidden_states(layer, **strip(retain_inputs)).float()
+            with torch.no_grad():
+                oracle_act = self.teacher_model.hidden_states(layer, **strip(retain_inputs)).float()
+            retain_loss = torch.nn.functional.mse_loss(retain_act, oracle_act)
+            loss = forget_loss + retain_loss
 
         else:
             raise ValueError(f"Invalid loss type {self.loss_type}")
 
-        loss = loss + self._l_norm_regulariser(model)
+        if not kwargs.get("_skip_reg", False):
+            loss = loss + self._l_norm_regulariser(model)
         return (loss, outputs) if return_outputs else loss
 
     # mm/trainer.py:451-481
@@ -238,3 +260,79 @@ class MMTrainerForgetting:
         with torch.no_grad():
             outputs = model(input_ids=input_ids, labels=labels, attention_mask=attention_mask)
         return (outputs.loss, outputs.logits, labels)
+
+
+class CustomTrainerForgetting(MMTrainerForgetting):
+    """Counterpart of the text trainer nlp/dataloader.py:93-485 (BASELINE config 1): same dispatcher on TUPLE inputs
+    `[forget, retain(, idk)]`, each `(input_ids, labels, attention_mask)` as custom_data_collator_forget builds them
+    (nlp/dataloader.py:497-517), `oracle_model` instead of `teacher_model`, CASE-SENSITIVE loss names as in the
+    reference ("KL", "LLMU", "RMU", "grad_diff_forget_KL_retain_ce"), and the text trainer's own formulas where they
+    differ from mm: NPO = 2/beta * mean(log(1 + log(p/p_T)^beta)) (:396-401), idk = ONE forward over cat(forget,
+    retain) with a single mean CE (:403-410), RMU with a fresh [1,1,H] control vector per call (:339-367), L1/L0
+    always against the oracle unless LoRA (:460-481).  The model is the same LlavaHIP run without pixel_values."""
+
+    def __init__(self, *args, **kwargs):
+        self.loss_type_raw = kwargs.get("forget_loss")
+        kwargs.setdefault("teacher_model", kwargs.pop("oracle_model", None))
+        kwargs.setdefault("l_norm_from", "init")
+        kwargs.setdefault("loss_args", {})
+        super().__init__(*args, **kwargs)
+        self.oracle_model = self.teacher_model
+
+    @staticmethod
+    def to_device(device, inputs):  # nlp/dataloader.py:140-142
+        return (inputs[0].to(device), inputs[1].to(device), inputs[2].to(device))
+
+    @staticmethod
+    def _split(t):
+        ids, labels, mask = t
+        return {"input_ids": ids, "attention_mask": mask, "labels": labels}
+
+    def compute_loss(self, model, inputs, return_outputs=False, *args, **kwargs):
+        forget_t, retain_t, *idk_t = inputs
+        dev = next(model.parameters()).device
+        f, r = self._split(self.to_device(dev, forget_t)), self._split(self.to_device(dev, retain_t))
+        nested = {"forget": f, "retain": r}
+        if idk_t:
+            nested["idk"] = self._split(self.to_device(dev, idk_t[0]))
+        lt, beta = self.loss_type_raw, self.loss_beta
+        outputs = None
+        if lt == "npo":
+            outputs = model(**f)
+            with torch.no_grad():
+                oracle = self.oracle_model(**f)
+            n = outputs.logits.numel()
+            from . import hip
+            from .llava import row_loss_sum
+            loss = 2 / beta * row_loss_sum(outputs.logits, oracle.logits, hip.NPO_NLP, beta) / n
+        elif lt == "idk":
+            cat = {k: torch.cat((f[k], r[k]), dim=0) for k in ("input_ids", "attention_mask", "labels")}
+            outputs = model(**cat)
+            loss = outputs.loss
+        elif lt == "RMU":
+            layer = int(self.loss_args.get("rmu_layer", 7))
+            strip = lambda d: {k: v for k, v in d.items() if k != "labels"}
+            fa = model.hidden_states(layer, **strip(f)).float()
+            cv = self.control_vec
+            if cv is None:  # the text trainer draws a new vector on every call (nlp/dataloader.py:347-354)
+                rand_vec = torch.rand(1, 1, fa.shape[-1], dtype=fa.dtype, device=fa.device)
+                cv = rand_vec / torch.norm(rand_vec) * 300
+            forget_loss = torch.nn.functional.mse_loss(fa, cv.to(fa.device).expand_as(fa)) * beta
+            ra = model.hidden_states(layer, **strip(r)).float()
+            with torch.no_grad():
+                oa = self.oracle_model.hidden_states(layer, **strip(r)).float()
+            loss = forget_loss + torch.nn.functional.mse_loss(ra, oa)
+        elif lt in ("retain_ft", "grad_ascent", "scrub", "eco_ft", "dpo", "KL", "LLMU") or lt.startswith("grad_diff"):
+            # identical arithmetic to the mm dispatcher (whose names are the lower-cased ones; "forget_KL" -> "forget_kl")
+            keep, self.loss_type = self.loss_type, lt.lower()
+            try:
+                if lt.startswith("grad_diff") and "forget_ce" not in lt and "forget_entropy" not in lt and "forget_KL" not in lt:
+                    raise ValueError(f"Invalid loss type on forget {lt}")
+                res = MMTrainerForgetting.compute_loss(self, model, nested, return_outputs=True, _skip_reg=True)
+            finally:
+                self.loss_type = keep
+            loss, outputs = res
+        else:
+            raise ValueError(f"Invalid loss type {lt}")
+        loss = loss + self._l_norm_regulariser(model)
+        return (loss, outputs) if return_outputs else loss

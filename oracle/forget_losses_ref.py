@@ -116,6 +116,16 @@ def compute_loss_ref(loss_type: str, student, teacher, inputs, loss_beta=1.0, im
         lg = remove_image_tokens(idk["input_ids"], io["logits"], image_token_index)
         idk_loss_current = -1 * get_batch_loss(lg, idk["labels"])
         return -idk_loss_current.mean()
+    if lt == "rmu":  # :302-326 — `student(x, capture_layer=k)["hidden"]` stands in for the forward hook on layers[k]
+        la = loss_args or {}
+        k = int(la.get("rmu_layer", 7))
+        fa = student(f, capture_layer=k)["hidden"]
+        cv = la["control_vec"]  # [B,1,H]; the reference draws it with torch.rand on first use and caches it
+        fl = F.mse_loss(fa.mean(dim=1), cv) * loss_beta  # [B,H] vs [B,1,H]: broadcasts to [B,B,H] as in the reference
+        ra = student(r, capture_layer=k)["hidden"]
+        with torch.no_grad():
+            oa = teacher(r, capture_layer=k)["hidden"]
+        return fl + F.mse_loss(ra, oa)
     if lt == "sku":  # :412-446
         la = loss_args or {}
         bad = student(f)["loss"]
@@ -147,3 +157,75 @@ def l1l0_ref(params, teacher_params, l1_lambda, l0_lambda, l_norm_from, has_lora
     if l0_lambda:
         out = out + l0_lambda * torch.norm(cat, p=0)
     return out
+
+
+def compute_loss_nlp_ref(loss_type: str, student, oracle, inputs, loss_beta=1.0, rand_vec=None, rmu_layer=7):
+    """nlp/dataloader.py:144-458 (text trainer, CASE-SENSITIVE names, tuple inputs already turned into dicts
+    {"input_ids","attention_mask","labels"} by the caller: [forget, retain(, idk)])."""
+    f, r, *rest = inputs
+    idk = rest[0] if rest else None
+    lt = loss_type
+
+    def T(x, **kw):
+        with torch.no_grad():
+            return oracle(x, **kw)
+
+    if lt == "retain_ft":
+        return student(r)["loss"]
+    if lt == "grad_ascent":
+        return -1 * student(f)["loss"]
+    if lt.startswith("grad_diff"):  # :167-225
+        fo, ro = student(f), student(r)
+        if "forget_ce" in lt:
+            fl = fo["loss"]
+        elif "forget_entropy" in lt:
+            p = logits2probs(fo["logits"], log=False)
+            fl = torch.sum(p * torch.log(p))
+        elif "forget_KL" in lt:
+            fl = _kl(logits2probs(fo["logits"]), logits2probs(T(f)["logits"]))
+        else:
+            raise ValueError(f"Invalid loss type on forget {lt}")
+        if "retain_ce" in lt:
+            rl = ro["loss"]
+        elif "retain_KL" in lt:
+            rl = _kl(logits2probs(ro["logits"]), logits2probs(T(r)["logits"]))
+        else:
+            raise ValueError(f"Invalid loss type on retain {lt}")
+        return -1 * loss_beta * fl + rl
+    if lt == "scrub":  # :227-269
+        fo = student(f)
+        klf = _kl(logits2probs(T(f)["logits"]), logits2probs(fo["logits"]))
+        ro = student(r)
+        klr = _kl(logits2probs(T(r)["logits"]), logits2probs(ro["logits"]))
+        return -1 * loss_beta * klf + klr + ro["loss"]
+    if lt == "KL":  # :271-301
+        fl = -1 * student(f)["loss"]
+        tr = logits2probs(T(r)["logits"])
+        return fl + _kl(logits2probs(student(r)["logits"]), tr)
+    if lt == "LLMU":  # :303-337
+        fl = -1 * student(f)["loss"]
+        rnd = student(idk)["loss"]
+        ro = student(r)
+        return fl + _kl(logits2probs(T(r)["logits"]), logits2probs(ro["logits"])) + rnd
+    if lt == "RMU":  # :339-367 — fresh [1,1,H] control vector each call
+        fa = student(f, capture_layer=rmu_layer)["hidden"]
+        cv = rand_vec / torch.norm(rand_vec) * 300
+        fl = F.mse_loss(fa, cv.expand_as(fa)) * loss_beta
+        ra = student(r, capture_layer=rmu_layer)["hidden"]
+        oa = T(r, capture_layer=rmu_layer)["hidden"]
+        return fl + F.mse_loss(ra, oa)
+    if lt == "npo":  # :384-401
+        fo = student(f)
+        tp = logits2probs(T(f)["logits"], log=False)
+        sp = logits2probs(fo["logits"], log=False)
+        pi = torch.log(sp / tp)
+        return 2 / loss_beta * torch.mean(torch.log(1 + pi ** loss_beta))
+    if lt == "idk":  # :403-410 — ONE forward over cat(forget, retain), one mean CE
+        cat = {k: torch.cat((f[k], r[k]), dim=0) for k in f}
+        return student(cat)["loss"]
+    if lt == "eco_ft":
+        return loss_beta * student(f)["loss"] + student(r)["loss"]
+    if lt == "dpo":  # :425-456 — effective loss after the overwrites
+        io = student(idk)
+        return -(-1 * get_batch_loss(io["logits"], idk["labels"])).mean()
+    raise ValueError(f"Invalid loss type {lt}")

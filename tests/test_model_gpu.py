@@ -243,3 +243,74 @@ def test_engine_rccl_path_single_rank(models, dev):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------ extra goldens: rmu / sku / nlp trainer
+@pytest.fixture(scope="module")
+def models8(dev):
+    from multimodal_unlearning_amd.llava import LlavaHIP
+
+    cfg = tiny_test_config(text_layers=8)
+    P = init_params(cfg, seed=0)
+    return cfg, LlavaHIP(cfg, P, device=dev), LlavaHIP(cfg, teacher_params_from(P, seed=7), device=dev, trainable=False)
+
+
+def _check_extra(g, tag, loss, student, tol_loss=1e-3, tol_g=2e-2):
+    ref = float(g[f"{tag}.loss"])
+    assert abs(loss.item() - ref) < tol_loss * max(1.0, abs(ref)), (tag, loss.item(), ref)
+    tot = student.ensure_grad().float().norm().item()
+    rt = float(g[f"{tag}.gradnorm.total"])
+    assert abs(tot - rt) < tol_g * rt, (tag, tot, rt)
+
+
+def test_rmu_and_sku_vs_reference_golden(models8):
+    from multimodal_unlearning_amd.trainer import MMTrainerForgetting
+
+    cfg, student, teacher = models8
+    g = np.load(os.path.join(G, "compute_loss_extra.npz"))
+    inputs = {s: {k: torch.from_numpy(g[f"mm.in.{s}.{k}"]) for k in KEYS} for s in ("forget", "retain", "idk")}
+    tr = MMTrainerForgetting(model=student, forget_loss="RMU", teacher_model=teacher, loss_beta=0.7, l1_lambda=0.0,
+                             l0_lambda=0.0, l_norm_from="zero", loss_args={})
+    tr.control_vec = torch.from_numpy(g["mm.rmu.control_vec"])
+    student.ensure_grad().zero_()
+    loss = tr.compute_loss(student, inputs)
+    loss.backward()
+    _check_extra(g, "mm.rmu", loss, student)
+    inputs["random"] = {k: torch.from_numpy(g[f"mm.in.random.{k}"]) for k in KEYS}
+    keep = {k: v.clone() for k, v in inputs["random"].items()}
+    tr = MMTrainerForgetting(model=student, forget_loss="sku", teacher_model=teacher, loss_beta=0.7, l1_lambda=0.0,
+                             l0_lambda=0.0, l_norm_from="zero",
+                             loss_args={"bad_weight": 2.5, "random_weight": 1.0, "normal_weight": 0.5})
+    student.ensure_grad().zero_()
+    loss = tr.compute_loss(student, inputs)
+    loss.backward()
+    _check_extra(g, "mm.sku", loss, student)
+    assert all(torch.equal(inputs["random"][k], keep[k]) for k in keep)  # inputs are not mutated (the reference does)
+
+
+NLP_TYPES = ["grad_ascent", "grad_diff_forget_ce_retain_ce", "grad_diff_forget_KL_retain_ce", "KL", "scrub", "npo", "idk",
+             "eco_ft", "dpo", "LLMU", "RMU"]
+
+
+@pytest.mark.parametrize("lt", NLP_TYPES)
+def test_nlp_tuple_trainer_vs_reference_golden(models8, lt):
+    """BASELINE config 1 surface: nlp/dataloader.py CustomTrainerForgetting on tuple inputs, text-only model."""
+    from multimodal_unlearning_amd.trainer import CustomTrainerForgetting
+
+    cfg, student, teacher = models8
+    g = np.load(os.path.join(G, "compute_loss_extra.npz"))
+    tup = [[torch.from_numpy(g[f"nlp.in.{s}.{k}"]) for k in ("input_ids", "labels", "attention_mask")]
+           for s in ("forget", "retain", "idk")]
+    tr = CustomTrainerForgetting(model=student, forget_loss=lt, oracle_model=teacher, loss_beta=2.0 if lt == "npo" else 0.7,
+                                 l1_lambda=0.0, l0_lambda=0.0)
+    if lt == "RMU":
+        rv = torch.from_numpy(g["nlp.RMU.rand_vec"])
+        tr.control_vec = rv / torch.norm(rv) * 300
+    student.ensure_grad().zero_()
+    loss = tr.compute_loss(student, tup)
+    loss.backward()
+    # the nlp NPO value is a mean of log(1 + log-ratio^2) ~ 4e-2: absolute 1e-3 of max(1,|loss|) still applies
+    _check_extra(g, f"nlp.{lt}", loss, student, tol_g=3e-2 if lt == "npo" else 2e-2)
+    with pytest.raises(ValueError):
+        CustomTrainerForgetting(model=student, forget_loss="kl", oracle_model=teacher, loss_beta=1.0, l1_lambda=0.0,
+                                l0_lambda=0.0).compute_loss(student, tup)  # the text trainer's names are case-sensitive
