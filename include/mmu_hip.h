@@ -27,6 +27,12 @@ int mmu_abi_version(void);
  *      (the rounding points of transformers' bf16 modules); accumulate=1: C = bf16(float(C) + acc). */
 int mmu_gemm_bf16(int layout, const void* A, const void* B, void* C, const void* bias, const void* resid,
                   int M, int N, int K, int lda, int ldb, int ldc, int ldr, int act, int accumulate, void* stream);
+/* mmu_gemm_bf16 plus a fused low-rank update acc += U[M][lora_k] * BL[N][lora_k]^T before the epilogue (peft LoRA,
+ * mm/forget.py:126-137: y = W x + (alpha/r) B (A x); U = (alpha/r) x A^T, BL = B).  U, BL: contiguous row-major
+ * bf16, lora_k in {32, 64}, unused columns zero (block structure of fused q|k|v and gate|up adapters). */
+int mmu_gemm_bf16_lora(int layout, const void* A, const void* B, void* C, const void* bias, const void* resid,
+                       int M, int N, int K, int lda, int ldb, int ldc, int ldr, int act, int accumulate,
+                       const void* lora_u, const void* lora_b, int lora_k, void* stream);
 /* Tile configuration override (A/B tests, tuning): 0 = heuristic, 128 = 128x128x64 4-wave kernel,
  * 256 = 256x256x64 8-wave 8-phase kernel.  Process-wide. */
 int mmu_gemm_set_tile(int tile);

@@ -42,6 +42,10 @@ struct GemmArgs {
     int accumulate;  // C = bf16(float(C) + acc) (grad accumulation)
     int tiles_m, tiles_n;
     int group_m;  // tile rasterisation: tiles of GROUP_M consecutive tile rows are swept column by column
+    // fused low-rank update (LoRA): acc += U[M][lora_k] * BL[N][lora_k]^T after the main K loop; lora_k in {0,32,64}
+    const bf16* lora_u;
+    const bf16* lora_b;
+    int lora_k;
 };
 
 __device__ __forceinline__ int swzT(int k) { return ((k & 3) << 1) | (((k >> 3) & 1) << 3); }
@@ -87,6 +91,17 @@ __device__ __forceinline__ bf16x8 read_frag(const MMU_LDS char* tile, int base, 
         bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((MMU_LDS bf16x4*)(a0 + 4 * 256));
         return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     }
+}
+
+// Fragment of a [rows][kl] row-major bf16 matrix straight from global memory (low-rank epilogue operands):
+// lane l holds row `row0 + (l&15)`, k = ks*32 + 8*(l>>4) + 0..7; rows past `rows` read as zeros.
+__device__ __forceinline__ bf16x8 global_frag(const bf16* __restrict__ base, int kl, int row0, int rows, int ks, int lane) {
+    const int r = row0 + (lane & 15);
+    bf16x8 z;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) z[j] = f2bf(0.f);
+    if (r >= rows) return z;
+    return *reinterpret_cast<const bf16x8*>(base + (size_t)r * kl + ks * 32 + 8 * (lane >> 4));
 }
 
 __device__ __forceinline__ float act_apply(float v, int act) {
@@ -184,6 +199,21 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
             for (int mt = 0; mt < 4; ++mt) af[mt] = read_frag<AT>(tA, wm * 64 + mt * 16, ks, lane);
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) bfr[nt] = read_frag<BT>(tB, wn * 64 + nt * 16, ks, lane);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nt], af[mt], acc[nt][mt], 0, 0, 0);
+        }
+    }
+
+    if (p.lora_k) {  // fused low-rank update
+        for (int ks = 0; ks < p.lora_k / 32; ++ks) {
+            bf16x8 af[4], bfr[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) af[mt] = global_frag(p.lora_u, p.lora_k, m0 + wm * 64 + mt * 16, p.M, ks, lane);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) bfr[nt] = global_frag(p.lora_b, p.lora_k, n0 + wn * 64 + nt * 16, p.N, ks, lane);
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -447,6 +477,33 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     if (wm == 0) G256_BAR();  // balance the stagger barrier
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the overrun prefetches before the LDS is released
 
+    if (p.lora_k) {  // fused low-rank update: acc += U[M][kl] * BL[N][kl]^T
+        for (int ks = 0; ks < p.lora_k / 32; ++ks) {
+            bf16x8 lu[2][4], lb[2][2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+                    lu[a][mt] = global_frag(p.lora_u, p.lora_k, m0 + wm * 128 + a * 64 + mt * 16, p.M, ks, lane);
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    lb[b][nt] = global_frag(p.lora_b, p.lora_k, n0 + (wn >> 1) * 128 + b * 64 + (wn & 1) * 32 + nt * 16, p.N,
+                                            ks, lane);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt)
+                            acc[a][b][nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lb[b][nt], lu[a][mt],
+                                                                                        acc[a][b][nt][mt], 0, 0, 0);
+        }
+    }
+
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -515,10 +572,25 @@ static bool pick_256(int M, int N, int K) {
 
 // C-ABI. layout: 0 = NT (A[M,K], B[N,K]); 1 = NN (A[M,K], B[K,N]); 2 = TN (A[K,M], B[K,N]).
 // Returns 0, a hipError_t, or -1 for an argument the kernel does not support.
+extern "C" int mmu_gemm_bf16_lora(int layout, const void* A, const void* B, void* C, const void* bias,
+                                  const void* resid, int M, int N, int K, int lda, int ldb, int ldc, int ldr, int act,
+                                  int accumulate, const void* lora_u, const void* lora_b, int lora_k, void* stream);
+
 extern "C" int mmu_gemm_bf16(int layout, const void* A, const void* B, void* C, const void* bias, const void* resid,
                              int M, int N, int K, int lda, int ldb, int ldc, int ldr, int act, int accumulate,
                              void* stream) {
+    return mmu_gemm_bf16_lora(layout, A, B, C, bias, resid, M, N, K, lda, ldb, ldc, ldr, act, accumulate, nullptr,
+                              nullptr, 0, stream);
+}
+
+// Same as mmu_gemm_bf16 plus a fused low-rank update acc += U[M][lora_k] * BL[N][lora_k]^T (both row-major,
+// contiguous, 16-B aligned; lora_k in {32, 64}; pad unused columns with zeros).  LoRA: U = s * x A^T, BL = B.
+extern "C" int mmu_gemm_bf16_lora(int layout, const void* A, const void* B, void* C, const void* bias,
+                                  const void* resid, int M, int N, int K, int lda, int ldb, int ldc, int ldr, int act,
+                                  int accumulate, const void* lora_u, const void* lora_b, int lora_k, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0) return -1;
+    if (lora_k != 0 && (lora_k != 32 && lora_k != 64)) return -1;
+    if (lora_k != 0 && (!lora_u || !lora_b || (((uintptr_t)lora_u | (uintptr_t)lora_b) & 15))) return -1;
     if ((N & 7) || (lda & 7) || (ldb & 7) || (ldc & 3) || (resid && (ldr & 3))) return -1;
     if (layout == 0 && (K & 7)) return -1;              // both operands K-contiguous: 16-B chunks along K
     if (layout == 1 && (K & 7)) return -1;              // A K-contiguous
@@ -530,6 +602,7 @@ extern "C" int mmu_gemm_bf16(int layout, const void* A, const void* B, void* C, 
     a.bias = (const bf16*)bias; a.resid = (const bf16*)resid;
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldr = ldr;
     a.act = act; a.accumulate = accumulate;
+    a.lora_u = (const bf16*)lora_u; a.lora_b = (const bf16*)lora_b; a.lora_k = lora_k;
     a.tiles_m = (M + BM - 1) / BM; a.tiles_n = (N + BN - 1) / BN;
     hipStream_t s = (hipStream_t)stream;
     if (pick_256(M, N, K)) {

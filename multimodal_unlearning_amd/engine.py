@@ -122,8 +122,7 @@ class ForgetEngine:
         self.hip.adamw(model.train_flat.data, self.grad, self.m, self.v, lr, self.cfg.adam_beta1, self.cfg.adam_beta2,
                        self.cfg.adam_eps, self.cfg.weight_decay, self.opt_step, self.sumsq, self.cfg.max_grad_norm,
                        1.0 / self.world, True)
-        if model.wT:
-            model.refresh_transposed_weights()
+        model.refresh_derived()  # W^T copies (full fine-tuning) or LoRA's scaled / transposed adapter copies
         mean_loss = (total / ga)
         if sync_loss:
             if self.world > 1:

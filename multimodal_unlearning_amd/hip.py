@@ -21,6 +21,7 @@ _vp, _i, _f, _ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
 SIGNATURES = {
     "mmu_abi_version": [],
     "mmu_gemm_bf16": [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "mmu_gemm_bf16_lora": [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp],
     "mmu_gemm_set_tile": [_i],
     "mmu_gemm_set_group_m": [_i],
     "mmu_attn_fwd": [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp],
@@ -103,9 +104,11 @@ NT, NN, TN = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_QUICK_GELU = 0, 1, 2
 
 
-def gemm(layout: int, A, B, out, *, bias=None, resid=None, act=0, accumulate=False, M=None, N=None, K=None):
-    """out[M,N] = epi(Aop @ Bop^T).  2-D tensors with unit inner stride; leading dims taken from strides."""
-    _bf16c(A, B, out, bias, resid)
+def gemm(layout: int, A, B, out, *, bias=None, resid=None, act=0, accumulate=False, M=None, N=None, K=None,
+         lora_u=None, lora_b=None):
+    """out[M,N] = epi(Aop @ Bop^T (+ lora_u @ lora_b^T)).  2-D tensors with unit inner stride; leading dims from
+    strides.  lora_u [M,kl], lora_b [N,kl] contiguous, kl in {32,64}: fused low-rank (LoRA) update."""
+    _bf16c(A, B, out, bias, resid, lora_u, lora_b)
     assert A.stride(-1) == 1 and B.stride(-1) == 1 and out.stride(-1) == 1
     if layout == NT:
         m, k = A.shape
@@ -121,6 +124,15 @@ def gemm(layout: int, A, B, out, *, bias=None, resid=None, act=0, accumulate=Fal
     N = n if N is None else N
     K = k if K is None else K
     assert out.shape[0] >= M and out.shape[1] >= N
+    if lora_u is not None:
+        kl = lora_u.shape[1]
+        assert lora_u.is_contiguous() and lora_b.is_contiguous() and lora_b.shape[1] == kl
+        assert lora_u.shape[0] >= M and lora_b.shape[0] >= N
+        rc = load().mmu_gemm_bf16_lora(layout, _p(A), _p(B), _p(out), _p(bias), _p(resid), M, N, K, A.stride(0),
+                                       B.stride(0), out.stride(0), resid.stride(0) if resid is not None else 0, act,
+                                       int(accumulate), _p(lora_u), _p(lora_b), kl, _stream())
+        _check(rc, "mmu_gemm_bf16_lora")
+        return out
     rc = load().mmu_gemm_bf16(layout, _p(A), _p(B), _p(out), _p(bias), _p(resid), M, N, K, A.stride(0), B.stride(0),
                               out.stride(0), resid.stride(0) if resid is not None else 0, act, int(accumulate),
                               _stream())

@@ -35,6 +35,26 @@ from .params import init_params, is_vision, param_specs
 BF = torch.bfloat16
 
 
+class LoraSpec:
+    """peft LoraConfig subset used by the reference (mm/forget.py:126-137; config/mm/forget.yaml:3-6): rank r,
+    alpha, dropout 0, bias "none".  Targets: decoder q|k|v, o, gate|up, down, lm_head (utils.py:10-19 only strips
+    the top-level name "lm_head", so under transformers 4.45.1 LLaVA's `language_model.lm_head` IS adapted) and the
+    two projector Linears.  The CLIP tower's Linears are NOT adapted here (that needs the CLIP backward; listed as
+    next in DESIGN.md) — `targets` makes the set explicit, as SURVEY.md §4 asks."""
+
+    def __init__(self, r: int = 8, alpha: float = 32.0, targets=("qkv", "o", "gate_up", "down", "lm_head", "projector")):
+        self.r, self.alpha, self.targets = int(r), float(alpha), tuple(targets)
+        self.scaling = self.alpha / self.r
+
+
+class _Adapter:
+    """One (possibly fused) LoRA module: y = x W^T + s * (x A^T) B^T.  A32 [kl,in] and BL [out,kl] are views of the
+    trainable flat buffer (kl = 32 or 64 >= k*r, zero padded; fused q|k|v / gate|up adapters are block-diagonal in
+    BL, enforced by `mask`).  Derived, refreshed after every optimiser step: A32s = s*A32, A32T = A32^T, BLs = s*BL."""
+    __slots__ = ("name", "k", "r", "kl", "A32", "BL", "gA", "gB", "mask", "A32s", "A32T", "BLs")
+
+
+
 class LlavaOutput:
     """Attribute + key access like transformers' ModelOutput (`.loss`, `.logits`)."""
 
@@ -136,7 +156,8 @@ def row_loss_sum(student_logits, teacher_logits, mode, beta=1.0):
 # --------------------------------------------------------------------------------------------------------
 class LlavaHIP(nn.Module):
     def __init__(self, cfg: LlavaConfig, params: Optional[Dict[str, torch.Tensor]] = None, device="cuda:0",
-                 seed: int = 0, freeze_vision: bool = True, trainable: bool = True, init: str = "numpy"):
+                 seed: int = 0, freeze_vision: bool = True, trainable: bool = True, init: str = "numpy",
+                 lora: Optional[LoraSpec] = None):
         super().__init__()
         if not freeze_vision:
             raise NotImplementedError("the vision tower is frozen in the forget step (mm/forget.py:117-118)")
@@ -158,13 +179,28 @@ class LlavaHIP(nn.Module):
                 self._off[name] = ("t", nt, shape)
                 nt += n
         self.register_buffer("frozen_flat", torch.zeros(nv, device=dev, dtype=BF), persistent=True)
-        self.train_flat = nn.Parameter(torch.zeros(nt, device=dev, dtype=BF), requires_grad=trainable)
+        self.lora_spec = lora
+        self.lora: Dict[str, _Adapter] = {}
+        self._base_flat = torch.zeros(nt, device=dev, dtype=BF)
         self.w: Dict[str, torch.Tensor] = OrderedDict()
         for name, (kind, off, shape) in self._off.items():
-            base = self.frozen_flat if kind == "v" else self.train_flat.data
+            base = self.frozen_flat if kind == "v" else self._base_flat
             self.w[name] = base[off:off + math.prod(shape)].view(shape)
+        # trainable flat buffer + name -> (offset, shape) of every trainable tensor inside it
+        self._toff: Dict[str, tuple] = OrderedDict()
+        if lora is None:
+            self.train_flat = nn.Parameter(self._base_flat, requires_grad=trainable)
+            for name, (kind, off, shape) in self._off.items():
+                if kind == "t":
+                    self._toff[name] = (off, shape)
+        else:
+            self.train_flat = nn.Parameter(self._build_lora(lora, dev), requires_grad=trainable)
         self._grad_flat: Optional[torch.Tensor] = None
         self.g: Dict[str, torch.Tensor] = OrderedDict()
+        self.wT: Dict[str, torch.Tensor] = {}
+        self._wT_flat: Optional[torch.Tensor] = None
+        self.transposed_wgrad = True
+        self.transposed_wgrad_min_m = 1024
         if params is not None:
             self.load_params(params)
         elif init == "device":
@@ -182,23 +218,144 @@ class LlavaHIP(nn.Module):
         # backward (used by the DP engine to start the RCCL all-reduce of a bucket while backward continues)
         self.grad_ready_hook: Optional[Callable[[int, int], None]] = None
         self.capture_layer: Optional[int] = None
-        # optional resident W^T copies of the decoder / lm_head weights (dgrad on the NT GEMM path)
-        self.wT: Dict[str, torch.Tensor] = {}
-        self._wT_flat: Optional[torch.Tensor] = None
-        self.transposed_wgrad = True
-        self.transposed_wgrad_min_m = 1024
+        if self.lora:
+            self.init_lora_(seed)
 
     # ------------------------------------------------------------------------------------------ params
     @property
     def device(self):
         return self.train_flat.device
 
+    # ------------------------------------------------------------------------------------------- LoRA
+    def _lora_targets(self, spec: LoraSpec):
+        t = self.cfg.text
+        out = []  # (weight name, k fused sub-modules)
+        if "projector" in spec.targets:
+            out += [("projector.linear_1.weight", 1), ("projector.linear_2.weight", 1)]
+        for i in range(t.num_layers):
+            p = f"text.layers.{i}."
+            for key, k in (("qkv", 3), ("o", 1), ("gate_up", 2), ("down", 1)):
+                if key in spec.targets:
+                    out.append((p + key + ".weight", k))
+        if "lm_head" in spec.targets:
+            out.append(("lm_head.weight", 1))
+        return out
+
+    def _build_lora(self, spec: LoraSpec, dev):
+        off = 0
+        plan = []
+        for wname, k in self._lora_targets(spec):
+            n_out, n_in = self._specs[wname]
+            kl = 32 if k * spec.r <= 32 else 64
+            if k * spec.r > 64:
+                raise ValueError("fused LoRA rank k*r > 64 is not supported by the GEMM epilogue")
+            base = wname[: -len(".weight")]
+            self._toff[base + ".lora_A"] = (off, (kl, n_in))
+            off += kl * n_in
+            self._toff[base + ".lora_B"] = (off, (n_out, kl))
+            off += n_out * kl
+            plan.append((wname, k, kl, n_out, n_in))
+        flat = torch.zeros(off, device=dev, dtype=BF)
+        for wname, k, kl, n_out, n_in in plan:
+            base = wname[: -len(".weight")]
+            ad = _Adapter()
+            ad.name, ad.k, ad.r, ad.kl = wname, k, spec.r, kl
+            oa, sa = self._toff[base + ".lora_A"]
+            ob, sb = self._toff[base + ".lora_B"]
+            ad.A32 = flat[oa:oa + kl * n_in].view(sa)
+            ad.BL = flat[ob:ob + n_out * kl].view(sb)
+            mask = torch.zeros(n_out, kl, device=dev, dtype=BF)
+            seg = n_out // k
+            for j in range(k):
+                mask[j * seg:(j + 1) * seg, j * spec.r:(j + 1) * spec.r] = 1
+            ad.mask = mask
+            ad.A32s = torch.zeros(kl, n_in, device=dev, dtype=BF)
+            ad.A32T = torch.zeros(n_in, kl, device=dev, dtype=BF)
+            ad.BLs = torch.zeros(n_out, kl, device=dev, dtype=BF)
+            ad.gA = ad.gB = None
+            self.lora[wname] = ad
+        return flat
+
+    def init_lora_(self, seed: int = 0, b_std: float = 0.0):
+        """peft init: A ~ kaiming_uniform(a=sqrt(5)) = U(-1/sqrt(in), 1/sqrt(in)) on the real rows, B = 0 (b_std > 0
+        draws B ~ N(0, b_std^2) inside its blocks: tests need a non-trivial adapter)."""
+        gen = torch.Generator(device=self.device).manual_seed(seed + 1000)
+        with torch.no_grad():
+            for ad in self.lora.values():
+                kl, n_in = ad.A32.shape
+                bound = 1.0 / math.sqrt(n_in)
+                ad.A32.zero_()
+                ad.A32[: ad.k * ad.r].uniform_(-bound, bound, generator=gen)
+                ad.BL.zero_()
+                if b_std > 0:
+                    ad.BL.normal_(0.0, b_std, generator=gen)
+                    ad.BL.mul_(ad.mask)
+        self.refresh_derived()
+
+    def refresh_derived(self):
+        """Recompute what depends on the trainable weights: LoRA's scaled / transposed adapter copies, or the
+        resident W^T copies in full fine-tuning.  The owner of the optimiser step calls this after every update."""
+        if self.lora:
+            s = self.lora_spec.scaling
+            with torch.no_grad():
+                for ad in self.lora.values():
+                    ad.A32s.copy_(ad.A32 * s)
+                    ad.A32T.copy_(ad.A32.t())
+                    ad.BLs.copy_(ad.BL * s)
+        elif self.wT:
+            self.refresh_transposed_weights()
+
+    def lora_state(self) -> "OrderedDict[str, torch.Tensor]":
+        """peft-shaped adapter tensors: <module>.lora_A [k*r, in] / lora_B [out, r] (compact, per fused module)."""
+        out = OrderedDict()
+        for wname, ad in self.lora.items():
+            base = wname[: -len(".weight")]
+            out[base + ".lora_A"] = ad.A32[: ad.k * ad.r].detach().float().cpu()
+            seg = ad.BL.shape[0] // ad.k
+            out[base + ".lora_B"] = torch.cat([ad.BL[j * seg:(j + 1) * seg, j * ad.r:(j + 1) * ad.r]
+                                               for j in range(ad.k)]).detach().float().cpu()
+        return out
+
+    def _lin_fwd(self, wname, x, out, bias=None, resid=None):
+        """out = x W^T (+ bias) (+ resid), plus the fused LoRA term when `wname` carries an adapter."""
+        ad = self.lora.get(wname)
+        if ad is None:
+            return hip.gemm(hip.NT, x, self.w[wname], out, bias=bias, resid=resid)
+        U = torch.empty(x.shape[0], ad.kl, device=x.device, dtype=BF)
+        hip.gemm(hip.NT, x, ad.A32s, U)  # s * x A^T
+        return hip.gemm(hip.NT, x, self.w[wname], out, bias=bias, resid=resid, lora_u=U, lora_b=ad.BL)
+
+    def _lin_bwd(self, wname, dy, x, dx):
+        """Backward of out = x W^T (+LoRA): accumulates the weight (or adapter) gradients, writes dx if given."""
+        ad = self.lora.get(wname)
+        if ad is None:
+            if not self.lora:  # full fine-tuning: the base weight is trainable
+                self._wgrad(dy, x, wname)
+            if dx is not None:
+                self._dgrad(dy, wname, dx)
+            return
+        M = dy.shape[0]
+        Vs = torch.empty(M, ad.kl, device=dy.device, dtype=BF)
+        hip.gemm(hip.NN, dy, ad.BLs, Vs)  # s * dy B
+        if dx is not None:
+            if wname in self.wT:
+                hip.gemm(hip.NT, dy, self.wT[wname], dx, lora_u=Vs, lora_b=ad.A32T)
+            else:
+                hip.gemm(hip.NN, dy, self.w[wname], dx, lora_u=Vs, lora_b=ad.A32T)
+        base = wname[: -len(".weight")]
+        hip.gemm(hip.TN, Vs, x, self.g[base + ".lora_A"], accumulate=True)  # dA = s (dy B)^T x
+        U = torch.empty(M, ad.kl, device=dy.device, dtype=BF)
+        hip.gemm(hip.NT, x, ad.A32s, U)
+        gB = self.g[base + ".lora_B"]
+        hip.gemm(hip.TN, dy, U, gB, accumulate=True)  # dB = s dy^T (x A^T); off-block entries are not parameters
+        gB.mul_(ad.mask)
+
     def init_random_(self, seed: int = 0, std: float = 0.02):
         """Random-init weights of the architecture, generated ON DEVICE (7B/13B: no host copy): N(0, std^2) for
         matrices / embeddings / biases, 1 for every norm weight (SURVEY.md §8d synthetic weights)."""
         gen = torch.Generator(device=self.device).manual_seed(seed)
         with torch.no_grad():
-            for flat in (self.frozen_flat, self.train_flat.data):
+            for flat in (self.frozen_flat, self._base_flat):
                 if flat.numel():
                     flat.normal_(0.0, std, generator=gen)
             for name, t in self.w.items():
@@ -215,16 +372,28 @@ class LlavaHIP(nn.Module):
         return OrderedDict((k, v.detach().float().cpu()) for k, v in self.w.items())
 
     def trainable_names(self):
-        return [n for n in self._specs if not is_vision(n)]
+        return list(self._toff)
 
     def range_of(self, name):
-        kind, off, shape = self._off[name]
+        off, shape = self._toff[name]
         return off, off + _align8(math.prod(shape))
 
+    def _span(self, prefix: str):
+        """[lo, hi) of the flat trainable/gradient buffer covered by the tensors whose name starts with `prefix`."""
+        r = [self.range_of(n) for n in self._toff if n.startswith(prefix)]
+        return (min(a for a, _ in r), max(b for _, b in r)) if r else None
+
     def layer_grad_range(self, i: int):
-        lo = self._off[f"text.layers.{i}.input_norm.weight"][1]
-        hi = self.range_of(f"text.layers.{i}.down.weight")[1]
-        return lo, hi
+        return self._span(f"text.layers.{i}.")
+
+    @staticmethod
+    def _is_above(name: str, layer: int) -> bool:
+        """True for trainable tensors that sit after decoder layer `layer` in the sweep (upper layers, norm, head)."""
+        if name.startswith("text.norm.") or name.startswith("lm_head."):
+            return True
+        if name.startswith("text.layers."):
+            return int(name.split(".")[2]) > layer
+        return False
 
     # -------------------------------------------------------------------------- transposed weight copies
     def _dgrad_weight_names(self):
@@ -240,7 +409,7 @@ class LlavaHIP(nn.Module):
         The owner of the optimiser step must call refresh_transposed_weights() after every weight update
         (ForgetEngine does); a stale copy silently gives stale gradients, hence opt-in."""
         if self._wT_flat is None:
-            names = self._dgrad_weight_names()
+            names = [n for n in self._dgrad_weight_names() if n in self.w]
             total = sum(self.w[n].numel() for n in names)
             self._wT_flat = torch.empty(total, device=self.device, dtype=BF)
             off = 0
@@ -283,9 +452,8 @@ class LlavaHIP(nn.Module):
             self._grad_flat.zero_()
             self.train_flat.grad = self._grad_flat
         if not self.g:
-            for name, (kind, off, shape) in self._off.items():
-                if kind == "t":
-                    self.g[name] = self._grad_flat[off:off + math.prod(shape)].view(shape)
+            for name, (off, shape) in self._toff.items():
+                self.g[name] = self._grad_flat[off:off + math.prod(shape)].view(shape)
         return self._grad_flat
 
     # ----------------------------------------------------------------------------------------- forward
@@ -360,11 +528,11 @@ class LlavaHIP(nn.Module):
         feats = h.view(n, T, dv)[:, 1:].reshape(n * npatch, dv)  # drop CLS ("default" select strategy)
         dt = cfg.text.hidden_size
         p1 = torch.empty(n * npatch, dt, device=dev, dtype=BF)
-        hip.gemm(hip.NT, feats, w["projector.linear_1.weight"], p1, bias=w["projector.linear_1.bias"])
+        self._lin_fwd("projector.linear_1.weight", feats, p1, bias=w["projector.linear_1.bias"])
         p1a = torch.empty_like(p1)
         hip.gelu_fwd(p1, p1a)
         img = torch.empty_like(p1)
-        hip.gemm(hip.NT, p1a, w["projector.linear_2.weight"], img, bias=w["projector.linear_2.bias"])
+        self._lin_fwd("projector.linear_2.weight", p1a, img, bias=w["projector.linear_2.bias"])
         return img, (feats, p1, p1a)
 
     def hidden_states(self, layer: int, input_ids=None, attention_mask=None, pixel_values=None, position_ids=None,
@@ -417,21 +585,21 @@ class LlavaHIP(nn.Module):
             rstd1 = torch.empty(M, device=dev, dtype=torch.float32)
             hip.rmsnorm_fwd(h, w[p + "input_norm.weight"], y, rstd1, t.rms_norm_eps)
             qkv = torch.empty(M, 3 * dt, device=dev, dtype=BF)
-            hip.gemm(hip.NT, y, w[p + "qkv.weight"], qkv)
+            self._lin_fwd(p + "qkv.weight", y, qkv)
             hip.rope(qkv, pos, self._cos, self._sin, H, H, D, dt)
             a = torch.empty(M, dt, device=dev, dtype=BF)
             lse = torch.empty(B, H, S, device=dev, dtype=torch.float32) if save else None
             hip.attn_fwd(qkv[:, :dt], qkv[:, dt:2 * dt], qkv[:, 2 * dt:], a, lse, kmask, B, S, H, D, scale, True)
             h2 = torch.empty(M, dt, device=dev, dtype=BF)
-            hip.gemm(hip.NT, a, w[p + "o.weight"], h2, resid=h)
+            self._lin_fwd(p + "o.weight", a, h2, resid=h)
             rstd2 = torch.empty(M, device=dev, dtype=torch.float32)
             hip.rmsnorm_fwd(h2, w[p + "post_norm.weight"], y, rstd2, t.rms_norm_eps)
             gu = torch.empty(M, 2 * I, device=dev, dtype=BF)
-            hip.gemm(hip.NT, y, w[p + "gate_up.weight"], gu)
+            self._lin_fwd(p + "gate_up.weight", y, gu)
             act = torch.empty(M, I, device=dev, dtype=BF)
             hip.swiglu_fwd(gu, act)
             hn = torch.empty(M, dt, device=dev, dtype=BF)
-            hip.gemm(hip.NT, act, w[p + "down.weight"], hn, resid=h2)
+            self._lin_fwd(p + "down.weight", act, hn, resid=h2)
             if save:
                 saved["layers"].append((h, rstd1, qkv, a, lse, h2, rstd2, gu))
             h = hn
@@ -442,7 +610,7 @@ class LlavaHIP(nn.Module):
         rstdf = torch.empty(M, device=dev, dtype=torch.float32)
         hip.rmsnorm_fwd(h, w["text.norm.weight"], y, rstdf, t.rms_norm_eps)
         logits = torch.empty(M, t.vocab_size, device=dev, dtype=BF)
-        hip.gemm(hip.NT, y, w["lm_head.weight"], logits)
+        self._lin_fwd("lm_head.weight", y, logits)
         if save:
             saved["final"] = (h, rstdf)
         return logits.view(B, S, t.vocab_size), saved
@@ -472,16 +640,17 @@ class LlavaHIP(nn.Module):
         if stop_layer is None:
             h, rstdf = saved["final"]
             hip.rmsnorm_fwd(h, w["text.norm.weight"], y, None, t.rms_norm_eps)
-            self._wgrad(dlog, y, "lm_head.weight")
-            self._dgrad(dlog, "lm_head.weight", dy)
+            self._lin_bwd("lm_head.weight", dlog, y, dy)
             dh = torch.empty(M, dt, device=dev, dtype=BF)
-            hip.rmsnorm_bwd(dy, h, w["text.norm.weight"], rstdf, None, dh, dw_part, g["text.norm.weight"], True)
+            hip.rmsnorm_bwd(dy, h, w["text.norm.weight"], rstdf, None, dh, dw_part, g.get("text.norm.weight"), True)
             top = t.num_layers - 1
         else:
             dh = dlog.clone()  # gradient of the captured activation; the layers above get no gradient
             top = stop_layer
-        if hook:
-            hook(self.layer_grad_range(top)[1], self.range_of("lm_head.weight")[1])
+        if hook:  # everything laid out after decoder layer `top` (upper layers, final norm, lm_head) is final
+            above = [self.range_of(n) for n in self._toff if self._is_above(n, top)]
+            if above:
+                hook(min(a for a, _ in above), max(b for _, b in above))
         delta = torch.empty(B, H, S, device=dev, dtype=torch.float32)
         layers = saved["layers"]
         for i in reversed(range(top + 1)):
@@ -491,36 +660,33 @@ class LlavaHIP(nn.Module):
             # MLP
             act = torch.empty(M, I, device=dev, dtype=BF)
             hip.swiglu_fwd(gu, act)
-            self._wgrad(dh, act, p + "down.weight")
             dact = torch.empty(M, I, device=dev, dtype=BF)
-            self._dgrad(dh, p + "down.weight", dact)
+            self._lin_bwd(p + "down.weight", dh, act, dact)
             dgu = torch.empty(M, 2 * I, device=dev, dtype=BF)
             hip.swiglu_bwd(gu, dact, dgu)
             del act, dact, gu
             hip.rmsnorm_fwd(h2, w[p + "post_norm.weight"], y, None, t.rms_norm_eps)
-            self._wgrad(dgu, y, p + "gate_up.weight")
-            self._dgrad(dgu, p + "gate_up.weight", dy)
+            self._lin_bwd(p + "gate_up.weight", dgu, y, dy)
             del dgu
             dh2 = torch.empty(M, dt, device=dev, dtype=BF)
-            hip.rmsnorm_bwd(dy, h2, w[p + "post_norm.weight"], rstd2, dh, dh2, dw_part, g[p + "post_norm.weight"], True)
+            hip.rmsnorm_bwd(dy, h2, w[p + "post_norm.weight"], rstd2, dh, dh2, dw_part, g.get(p + "post_norm.weight"),
+                            True)
             # attention
-            self._wgrad(dh2, a, p + "o.weight")
             da = dh  # reuse the buffer of the (now consumed) upstream gradient
-            self._dgrad(dh2, p + "o.weight", da)
+            self._lin_bwd(p + "o.weight", dh2, a, da)
             dqkv = torch.empty(M, 3 * dt, device=dev, dtype=BF)
             hip.attn_bwd(qkv[:, :dt], qkv[:, dt:2 * dt], qkv[:, 2 * dt:], a, lse, saved["kmask"], da, delta,
                          dqkv[:, :dt], dqkv[:, dt:2 * dt], dqkv[:, 2 * dt:], B, S, H, D, scale, True)
             hip.rope(dqkv, saved["pos"], self._cos, self._sin, H, H, D, dt, inverse=True)
             del qkv, a
             hip.rmsnorm_fwd(hin, w[p + "input_norm.weight"], y, None, t.rms_norm_eps)
-            self._wgrad(dqkv, y, p + "qkv.weight")
-            self._dgrad(dqkv, p + "qkv.weight", dy)
+            self._lin_bwd(p + "qkv.weight", dqkv, y, dy)
             del dqkv
             dh = da  # overwrite: da is dead after attn_bwd
-            hip.rmsnorm_bwd(dy, hin, w[p + "input_norm.weight"], rstd1, dh2, dh, dw_part, g[p + "input_norm.weight"],
-                            True)
+            hip.rmsnorm_bwd(dy, hin, w[p + "input_norm.weight"], rstd1, dh2, dh, dw_part,
+                            g.get(p + "input_norm.weight"), True)
             del dh2, hin, h2
-            if hook:
+            if hook and self.layer_grad_range(i):
                 hook(*self.layer_grad_range(i))
         # embeddings / projector
         slot = saved["slot"]
@@ -532,20 +698,24 @@ class LlavaHIP(nn.Module):
             self._embed_scratch = torch.zeros(V, dt, device=dev, dtype=torch.float32)
             self._embed_flag = torch.zeros(V, device=dev, dtype=torch.int32)
         hip.embed_bwd(saved["ids"].view(-1), slot, dh, dimg, self._embed_scratch, self._embed_flag,
-                      g["text.embed_tokens.weight"], V)
-        if dimg is not None:
+                      g.get("text.embed_tokens.weight"), V)
+        full = not self.lora
+        if dimg is not None and (full or "projector.linear_2.weight" in self.lora or "projector.linear_1.weight" in self.lora):
             n = dimg.shape[0]
             cpart = torch.empty(hip.colsum_nparts(n) * dt, device=dev, dtype=torch.float32)
-            hip.gemm(hip.TN, dimg, p1a, g["projector.linear_2.weight"], accumulate=True)
-            hip.colsum(dimg, cpart, g["projector.linear_2.bias"], True)
             dp1a = torch.empty_like(p1)
-            hip.gemm(hip.NN, dimg, w["projector.linear_2.weight"], dp1a)
+            self._lin_bwd("projector.linear_2.weight", dimg, p1a, dp1a)
+            if full:
+                hip.colsum(dimg, cpart, g["projector.linear_2.bias"], True)
             dp1 = torch.empty_like(p1)
             hip.gelu_bwd(p1, dp1a, dp1)
-            hip.gemm(hip.TN, dp1, feats, g["projector.linear_1.weight"], accumulate=True)
-            hip.colsum(dp1, cpart, g["projector.linear_1.bias"], True)
-        if hook:
-            hook(0, self.range_of("text.embed_tokens.weight")[1])
+            self._lin_bwd("projector.linear_1.weight", dp1, feats, None)
+            if full:
+                hip.colsum(dp1, cpart, g["projector.linear_1.bias"], True)
+        if hook:  # everything laid out before decoder layer 0 (projector, token embedding)
+            below = [self.range_of(n) for n in self._toff if n.startswith("projector.") or n.startswith("text.embed_tokens")]
+            if below:
+                hook(min(a for a, _ in below), max(b for _, b in below))
 
 
 class _LlavaFn(torch.autograd.Function):

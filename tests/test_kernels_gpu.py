@@ -498,3 +498,21 @@ def test_transpose(dev):
         y = torch.full((Cc, R), 3.0, device=dev, dtype=BF)
         hip.transpose(x, y)
         assert torch.equal(y, x.t().contiguous()), (R, Cc)
+
+
+@pytest.mark.parametrize("tile", [128, 256])
+@pytest.mark.parametrize("kl", [32, 64])
+def test_gemm_fused_lowrank_update(dev, tile, kl):
+    """out = x W^T + U BL^T with the rank-kl term applied inside the GEMM (LoRA epilogue); integer data -> exact."""
+    hip.gemm_set_tile(tile)
+    M, N, K = 300, 264, 192
+    x, w = _rand_int((M, K), dev, seed=1), _rand_int((N, K), dev, seed=2)
+    u, bl = _rand_int((M, kl), dev, seed=3), _rand_int((N, kl), dev, seed=4)
+    bl[:, 24:] = 0  # zero padding columns, as the fused q|k|v adapters leave them
+    ref = (x.float() @ w.float().t() + u.float() @ bl.float().t()).to(BF)
+    out = torch.empty(M, N, device=dev, dtype=BF)
+    hip.gemm(hip.NT, x, w, out, lora_u=u, lora_b=bl)
+    assert torch.equal(out, ref)
+    res = _rand_int((M, N), dev, seed=5)
+    hip.gemm(hip.NT, x, w, out, resid=res, lora_u=u, lora_b=bl)
+    assert torch.equal(out, (ref.float() + res.float()).to(BF))

@@ -314,3 +314,69 @@ def test_nlp_tuple_trainer_vs_reference_golden(models8, lt):
     with pytest.raises(ValueError):
         CustomTrainerForgetting(model=student, forget_loss="kl", oracle_model=teacher, loss_beta=1.0, l1_lambda=0.0,
                                 l0_lambda=0.0).compute_loss(student, tup)  # the text trainer's names are case-sensitive
+
+
+# --------------------------------------------------------------------------------------------------- LoRA
+def test_lora_grad_ascent_vs_oracle(dev):
+    """BASELINE config 2 surface (grad_ascent, LoRA r=8 alpha=32 on decoder + projector + lm_head Linears).  peft is not
+    installed in this image, so the adapter arithmetic is pinned to the published LoRA formula
+    y = W x + (alpha/r) B A x through the fp32 oracle run on W_eff = W + (alpha/r) B A (parity unpinned vs peft)."""
+    from multimodal_unlearning_amd.llava import LlavaHIP, LoraSpec
+    from multimodal_unlearning_amd.trainer import MMTrainerForgetting
+    from oracle.llava_ref import llava_forward
+
+    cfg = tiny_test_config()
+    P = init_params(cfg, seed=0)
+    spec = LoraSpec(r=8, alpha=32.0)
+    model = LlavaHIP(cfg, P, device=dev, lora=spec)
+    model.init_lora_(seed=3, b_std=0.02)
+    assert model.train_flat.numel() < 0.2 * sum(v.numel() for v in P.values())
+    inputs = make_forget_batch(cfg, 2, 40, seed=21, n_question=7)
+    tr = MMTrainerForgetting(model=model, forget_loss="grad_ascent", teacher_model=None, loss_beta=1.0, l1_lambda=0,
+                             l0_lambda=0, l_norm_from="zero")
+    model.ensure_grad().zero_()
+    loss = tr.compute_loss(model, inputs)
+    loss.backward()
+    torch.cuda.synchronize()
+    # oracle on merged weights, adapters as fp32 leaves
+    leaves = {}
+    Pe = {k: v.clone() for k, v in P.items()}
+    for wname, ad in model.lora.items():
+        A = ad.A32.detach().float().cpu().requires_grad_(True)
+        Bm = ad.BL.detach().float().cpu().requires_grad_(True)
+        leaves[wname] = (A, Bm, ad.mask.float().cpu())
+        Pe[wname] = P[wname] + spec.scaling * (Bm @ A)
+    ref = -llava_forward(cfg, Pe, **inputs["forget"])["loss"]
+    ref.backward()
+    assert abs(loss.item() - ref.item()) < 1e-3 * max(1.0, abs(ref.item())), (loss.item(), ref.item())
+    num = den = 0.0
+    for wname, (A, Bm, mask) in leaves.items():
+        base = wname[: -len(".weight")]
+        gA, gB = model.g[base + ".lora_A"].float().cpu(), model.g[base + ".lora_B"].float().cpu()
+        rB = Bm.grad * mask
+        for got, exp in ((gA, A.grad), (gB, rB)):
+            num += float((got - exp).pow(2).sum())
+            den += float(exp.pow(2).sum())
+        assert float((gB * (1 - mask)).abs().max()) == 0.0  # off-block entries are not parameters
+    assert (num / den) ** 0.5 < 3e-2, (num / den) ** 0.5
+    st = model.lora_state()
+    assert st["text.layers.0.qkv.lora_A"].shape == (24, cfg.text.hidden_size)
+    assert st["text.layers.0.qkv.lora_B"].shape == (3 * cfg.text.hidden_size, 8)
+
+
+def test_lora_engine_step_trains_only_adapters(dev):
+    from multimodal_unlearning_amd.engine import ForgetEngine
+    from multimodal_unlearning_amd.llava import LlavaHIP, LoraSpec
+    from multimodal_unlearning_amd.trainer import MMTrainerForgetting
+
+    cfg = tiny_test_config()
+    P = init_params(cfg, seed=0)
+    model = LlavaHIP(cfg, P, device=dev, lora=LoraSpec(r=8, alpha=32.0))
+    base0 = model._base_flat.clone()
+    tr = MMTrainerForgetting(model=model, forget_loss="retain_ft", teacher_model=None, loss_beta=1.0, l1_lambda=0,
+                             l0_lambda=0, l_norm_from="zero")
+    eng = ForgetEngine(model, tr, ForgetConfig(lr=5e-3, weight_decay=0.0), total_steps=60, warmup_steps=2)
+    mbs = [make_forget_batch(cfg, 2, 32, seed=s, n_question=5) for s in (1, 2)]
+    losses = [eng.step(mbs, sync_loss=True).loss for _ in range(10)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0] - 0.2, losses
+    assert torch.equal(model._base_flat, base0)  # frozen base weights untouched
