@@ -31,7 +31,7 @@ import torch.distributed as dist  # noqa: E402
 PEAK_BF16 = 2.5e15  # dense bf16 MFMA FLOP/s per MI355X
 
 
-def flops_per_sample(cfg, S, paired=True):
+def flops_per_sample(cfg, S, paired=True, lora=False):
     """Algorithmic FLOPs of one grad_diff full-FT sample (forget + retain sequence), vision tower frozen:
     matmul = 2mnk, causal attention at half the dense S^2."""
     t, v = cfg.text, cfg.vision
@@ -45,7 +45,7 @@ def flops_per_sample(cfg, S, paired=True):
     clip = cfg.vision_layers_used * (2 * T * (4 * dv * dv + 2 * dv * iv) + 2 * 2 * T * T * dv) + 2 * v.num_patches * v.patch_k * dv
     proj = 2 * v.num_patches * (dv * d + d * d)
     fwd = dec + clip + proj
-    fb = fwd + 2 * (dec + proj)
+    fb = fwd + (1 if lora else 2) * (dec + proj)  # LoRA: dgrad only (adapter GEMMs are < 1 %)
     return (2 if paired else 1) * fb
 
 
@@ -172,6 +172,8 @@ def main():
     ap.add_argument("--layers", type=int, default=0, help="debug: override decoder depth (invalidates the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fuse", action="store_true")
+    ap.add_argument("--lora-r", type=int, default=0, help="LoRA rank (0 = full fine-tuning); BASELINE config 2 uses 8")
+    ap.add_argument("--lora-alpha", type=float, default=32.0)
     args = ap.parse_args()
 
     from multimodal_unlearning_amd import hip
@@ -190,7 +192,11 @@ def main():
     cfg = {"7b": llava_1_5_7b, "13b": llava_1_5_13b, "tiny": tiny_test_config}[args.model]()
     if args.layers:
         cfg.text.num_layers = args.layers
-    model = LlavaHIP(cfg, device=dev, init="device", seed=0)
+    lora = None
+    if args.lora_r:
+        from multimodal_unlearning_amd.llava import LoraSpec
+        lora = LoraSpec(r=args.lora_r, alpha=args.lora_alpha)
+    model = LlavaHIP(cfg, device=dev, init="device", seed=0, lora=lora)
     needs_teacher = any(k in args.loss.lower() for k in ("kl", "npo", "scrub", "dpo", "llmu"))
     teacher = LlavaHIP(cfg, device=dev, init="device", seed=1, trainable=False) if needs_teacher else None
     splits = ("forget", "retain", "idk") if any(k in args.loss.lower() for k in ("idk", "dpo", "llmu")) else ("forget", "retain")
@@ -236,17 +242,18 @@ def main():
     if rank == 0:
         samples = world * B * GA * args.steps
         value = samples / elapsed
-        fps = flops_per_sample(cfg, S)
+        paired = args.loss.lower() not in ("grad_ascent", "retain_ft")
+        fps = flops_per_sample(cfg, S, paired=paired, lora=bool(args.lora_r))
         f, t, n, by = timer.summary()
         out = {
             "metric": "forget-step samples/sec (img+text pairs) LLaVA-1.5-7B grad_diff",
             "value": round(value, 4), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"LLaVA-1.5-{args.model} {args.loss} full-FT (CLIP frozen), S={S} (576 image + 512 text "
+            "config": {"workload": f"LLaVA-1.5-{args.model} {args.loss} {'LoRA r=%d' % args.lora_r if args.lora_r else 'full-FT'} (CLIP frozen), S={S} (576 image + 512 text "
                                    f"tokens), image 336, random-init weights", "micro_batch_pairs_per_gpu": B,
                        "grad_accum": GA, "global_batch": world * B * GA, "seq_len": S, "parallelism": f"dp{world}",
-                       "paired_fusion": not args.no_fuse, "optimizer": "AdamW fp32 moments, clip 1.0",
+                       "paired_fusion": not args.no_fuse, "optimizer": "AdamW fp32 moments, clip 1.0", "lora_r": args.lora_r,
                        "decoder_layers": cfg.text.num_layers},
             "step_tflops_per_gpu": round(value * fps / world / 1e12, 1),
             "step_frac_of_mfma_peak": round(value * fps / world / PEAK_BF16, 4),

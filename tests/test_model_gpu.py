@@ -380,3 +380,40 @@ def test_lora_engine_step_trains_only_adapters(dev):
     losses = [eng.step(mbs, sync_loss=True).loss for _ in range(10)]
     assert all(np.isfinite(losses)) and losses[-1] < losses[0] - 0.2, losses
     assert torch.equal(model._base_flat, base0)  # frozen base weights untouched
+
+
+def test_eval_truth_ratio_pass_vs_reference_golden(models):
+    """mm/eval.py:46-92 on the HIP model vs the reference's own output (tests/golden/eval_tiny.json, generated by
+    oracle/make_golden_eval.py), then the forget-quality metric computed from both logs."""
+    import json
+
+    from multimodal_unlearning_amd import metrics
+    from multimodal_unlearning_amd.eval_util import eval_perturbation_ratio
+    from multimodal_unlearning_amd.synthetic import make_split
+
+    cfg, P, student, _ = models
+    gold = json.load(open(os.path.join(G, "eval_tiny.json")))
+    B, K, T = gold["seeds"]["B"], gold["seeds"]["K"], gold["seeds"]["T"]
+    batches, pbatches = [], []
+    for it in range(2):
+        sp = make_split(cfg, B, T, seed=700 + it, n_question=6)
+        sp["indices"] = torch.arange(B) + it * B
+        ps = [make_split(cfg, B, T, seed=800 + 10 * it + k, n_question=6) for k in range(K)]
+        pb = {k: torch.stack([p[k] for p in ps], dim=1) for k in ps[0]}
+        pb["pixel_values"] = pb["pixel_values"].reshape(B * K, *ps[0]["pixel_values"].shape[1:])
+        pb["indices"] = sp["indices"].clone()
+        batches.append(sp)
+        pbatches.append(pb)
+    logs = eval_perturbation_ratio(batches, pbatches, student)
+    for key in ("avg_paraphrased_loss", "truth_ratio", "paraphrased_loss"):
+        for i, v in gold["logs"][key].items():
+            got = logs[key][int(i)]
+            assert abs(got - v) < 2e-3 * max(1.0, abs(v)), (key, i, got, v)
+    for i, v in gold["logs"]["average_perturb_loss"].items():
+        assert max(abs(a - b) for a, b in zip(logs["average_perturb_loss"][int(i)], v)) < 2e-2
+    assert {int(i): v for i, v in gold["logs"]["num_token_perturb"].items()} == dict(logs["num_token_perturb"])
+    # metric on (our log vs the reference's log) must see "the same model": KS p-value 1, JS distance ~ 0
+    as_log = lambda d: {"eval_log_forget.json": {k: {str(i): v for i, v in d[k].items()} for k in
+                                                 ("avg_paraphrased_loss", "average_perturb_loss")}}
+    fq = metrics.evaluate_forget_quality(as_log(logs), {"eval_log_forget.json": gold["logs"]})
+    assert fq["KS test p-value"] > 0.99 and fq["JS metric"] < 1e-3, fq
