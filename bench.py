@@ -262,7 +262,7 @@ def main():
                          "launches": n, "avg_launch_us": round(t / n * 1e6, 1),
                          "gemm_share_of_step": round(t / (elapsed / args.steps), 3), "by_layout": by},
         }
-        if not args.no_cpu_baseline and args.model != "tiny":
+        if not args.no_cpu_baseline and args.model != "tiny" and world == 1:  # rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(cfg, S)
         elif args.model == "tiny":
             out["cpu_baseline"] = None

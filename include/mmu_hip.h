@@ -75,6 +75,11 @@ int mmu_gelu_bwd(const void* x, const void* dy, void* dx, long long n, void* str
 int mmu_add_bf16(const void* a, const void* b, void* out, long long n, void* stream);
 /* dst[C][R] = src[R][C]^T: keeps W^T resident so dgrad runs on the NT GEMM path. */
 int mmu_transpose_bf16(const void* src, void* dst, int R, int C, void* stream);
+/* Fused producers of TRANSPOSED wgrad operands (the NT wgrad path reads X^T / dY^T): SwiGLU recompute -> act^T
+ * [I][M]; RMSNorm recompute from the saved rstd -> y^T [d][M]; SwiGLU backward -> dgu [M][2I] and dgu^T [2I][M]. */
+int mmu_swiglu_fwd_t(const void* gate_up, void* actT, int M, int I, void* stream);
+int mmu_rmsnorm_apply_t(const void* x, const void* w, const float* rstd, void* yT, int M, int d, void* stream);
+int mmu_swiglu_bwd_t(const void* gate_up, const void* dh, void* dgate_up, void* dgate_upT, int M, int I, void* stream);
 int mmu_colsum_nparts(int M); /* part must hold nparts*d floats */
 int mmu_colsum_bf16(const void* x, float* part, void* dst, int accumulate, int M, int d, void* stream);
 

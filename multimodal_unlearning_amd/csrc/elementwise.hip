@@ -515,6 +515,80 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16* __restrict__
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Fused "elementwise producer -> transposed output" kernels: a 64x64 tile is computed in registers, staged in
+// LDS and written transposed ([cols][rows], 16-B stores), so the wgrad operands X^T / dY^T come out of their
+// producers directly instead of a separate transpose pass (saves a full write + read of the tensor).
+// MODE 0: act^T  = (bf16(silu(g)) * u)^T              from gate|up [M][2I]            (SwiGLU recompute in backward)
+// MODE 1: y^T    = (w * bf16(x * rstd))^T             from x [M][d], w [d], rstd [M]   (RMSNorm recompute in backward)
+// MODE 2: dgu and dgu^T from gate|up and dh           (SwiGLU backward: both layouts are consumed)
+// R rows (tokens), C columns of the OUTPUT of the elementwise op; R % 8 == 0, C % 8 == 0.
+// ------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void fused_t_kernel(const bf16* __restrict__ in0, const bf16* __restrict__ in1,
+                                                      const float* __restrict__ rstd, bf16* __restrict__ out_n,
+                                                      bf16* __restrict__ out_t, int R, int C) {
+    __shared__ bf16 tile[(MODE == 2 ? 2 : 1)][64][72];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tr = threadIdx.x >> 3, tc = (threadIdx.x & 7) * 8;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int r = r0 + tr + p * 32, c = c0 + tc;
+        bf16x8 o0, o1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { o0[j] = f2bf(0.f); o1[j] = f2bf(0.f); }
+        if (r < R && c < C) {
+            if (MODE == 0) {
+                const bf16x8 g = *reinterpret_cast<const bf16x8*>(in0 + (size_t)r * 2 * C + c);
+                const bf16x8 u = *reinterpret_cast<const bf16x8*>(in0 + (size_t)r * 2 * C + C + c);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float gf = bf2f(g[j]);
+                    o0[j] = f2bf(round_bf16(gf / (1.0f + __expf(-gf))) * bf2f(u[j]));
+                }
+            } else if (MODE == 1) {
+                const bf16x8 x = *reinterpret_cast<const bf16x8*>(in0 + (size_t)r * C + c);
+                const bf16x8 w = *reinterpret_cast<const bf16x8*>(in1 + c);
+                const float rs = rstd[r];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o0[j] = f2bf(bf2f(w[j]) * round_bf16(bf2f(x[j]) * rs));
+            } else {
+                const bf16x8 g = *reinterpret_cast<const bf16x8*>(in0 + (size_t)r * 2 * C + c);
+                const bf16x8 u = *reinterpret_cast<const bf16x8*>(in0 + (size_t)r * 2 * C + C + c);
+                const bf16x8 d = *reinterpret_cast<const bf16x8*>(in1 + (size_t)r * C + c);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float gf = bf2f(g[j]), uf = bf2f(u[j]), df = bf2f(d[j]);
+                    const float sig = 1.0f / (1.0f + __expf(-gf));
+                    o1[j] = f2bf(df * round_bf16(gf * sig));                      // d up
+                    o0[j] = f2bf(df * uf * (sig * (1.0f + gf * (1.0f - sig))));   // d gate
+                }
+                *reinterpret_cast<bf16x8*>(out_n + (size_t)r * 2 * C + c) = o0;
+                *reinterpret_cast<bf16x8*>(out_n + (size_t)r * 2 * C + C + c) = o1;
+            }
+        }
+        *reinterpret_cast<bf16x8*>(&tile[0][tr + p * 32][tc]) = o0;
+        if (MODE == 2) *reinterpret_cast<bf16x8*>(&tile[MODE == 2 ? 1 : 0][tr + p * 32][tc]) = o1;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int c = c0 + tr + p * 32, r = r0 + tc;  // output row = source column
+        if (c < C && r < R) {
+            bf16x8 v;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = tile[0][tc + j][tr + p * 32];
+            *reinterpret_cast<bf16x8*>(out_t + (size_t)c * R + r) = v;
+            if (MODE == 2) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = tile[MODE == 2 ? 1 : 0][tc + j][tr + p * 32];
+                *reinterpret_cast<bf16x8*>(out_t + (size_t)(C + c) * R + r) = v;
+            }
+        }
+    }
+}
+
 inline int grid_for(size_t work_items, int block) {
     size_t g = (work_items + block - 1) / block;
     if (g > 2048) g = 2048;  // 256 CUs x 8 blocks, grid-stride the rest
@@ -734,6 +808,31 @@ extern "C" int mmu_transpose_bf16(const void* src, void* dst, int R, int C, void
     if (R <= 0 || C <= 0 || (R & 7) || (C & 7)) return -1;
     hipLaunchKernelGGL(transpose_kernel, dim3((C + 63) / 64, (R + 63) / 64), dim3(256), 0, (hipStream_t)stream,
                        (const bf16*)src, (bf16*)dst, R, C);
+    MMU_CHECK_LAUNCH();
+    return 0;
+}
+
+// act^T [I][M] = swiglu(gate|up [M][2I])^T
+extern "C" int mmu_swiglu_fwd_t(const void* gu, void* actT, int M, int I, void* stream) {
+    if (M <= 0 || (I & 7) || (M & 7)) return -1;
+    hipLaunchKernelGGL(fused_t_kernel<0>, dim3((I + 63) / 64, (M + 63) / 64), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16*)gu, (const bf16*)nullptr, (const float*)nullptr, (bf16*)nullptr, (bf16*)actT, M, I);
+    MMU_CHECK_LAUNCH();
+    return 0;
+}
+// y^T [d][M] = (w * bf16(x * rstd))^T  (RMSNorm output recomputed from the saved rstd)
+extern "C" int mmu_rmsnorm_apply_t(const void* x, const void* w, const float* rstd, void* yT, int M, int d, void* stream) {
+    if (M <= 0 || (d & 7) || (M & 7)) return -1;
+    hipLaunchKernelGGL(fused_t_kernel<1>, dim3((d + 63) / 64, (M + 63) / 64), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16*)x, (const bf16*)w, rstd, (bf16*)nullptr, (bf16*)yT, M, d);
+    MMU_CHECK_LAUNCH();
+    return 0;
+}
+// dgu [M][2I] and dgu^T [2I][M] from gate|up and dh
+extern "C" int mmu_swiglu_bwd_t(const void* gu, const void* dh, void* dgu, void* dguT, int M, int I, void* stream) {
+    if (M <= 0 || (I & 7) || (M & 7)) return -1;
+    hipLaunchKernelGGL(fused_t_kernel<2>, dim3((I + 63) / 64, (M + 63) / 64), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16*)gu, (const bf16*)dh, (const float*)nullptr, (bf16*)dgu, (bf16*)dguT, M, I);
     MMU_CHECK_LAUNCH();
     return 0;
 }

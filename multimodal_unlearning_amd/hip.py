@@ -41,6 +41,9 @@ SIGNATURES = {
     "mmu_gelu_bwd": [_vp, _vp, _vp, _ll, _vp],
     "mmu_add_bf16": [_vp, _vp, _vp, _ll, _vp],
     "mmu_transpose_bf16": [_vp, _vp, _i, _i, _vp],
+    "mmu_swiglu_fwd_t": [_vp, _vp, _i, _i, _vp],
+    "mmu_rmsnorm_apply_t": [_vp, _vp, _vp, _vp, _i, _i, _vp],
+    "mmu_swiglu_bwd_t": [_vp, _vp, _vp, _vp, _i, _i, _vp],
     "mmu_colsum_nparts": [_i],
     "mmu_colsum_bf16": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "mmu_image_slots": [_vp, _i, _ll, _vp, _vp, _vp],
@@ -264,6 +267,26 @@ def transpose(src, dst):
     assert src.is_contiguous() and dst.is_contiguous() and tuple(dst.shape) == (Cc, R)
     _check(load().mmu_transpose_bf16(_p(src), _p(dst), R, Cc, _stream()), "mmu_transpose_bf16")
     return dst
+
+
+def swiglu_fwd_t(gu, actT):
+    _bf16c(gu, actT)
+    M, I2 = gu.shape
+    _check(load().mmu_swiglu_fwd_t(_p(gu), _p(actT), M, I2 // 2, _stream()), "mmu_swiglu_fwd_t")
+    return actT
+
+
+def rmsnorm_apply_t(x, w, rstd, yT):
+    _bf16c(x, w, yT)
+    M, d = x.shape
+    _check(load().mmu_rmsnorm_apply_t(_p(x), _p(w), _p(rstd), _p(yT), M, d, _stream()), "mmu_rmsnorm_apply_t")
+    return yT
+
+
+def swiglu_bwd_t(gu, dh, dgu, dguT):
+    _bf16c(gu, dh, dgu, dguT)
+    M, I2 = gu.shape
+    _check(load().mmu_swiglu_bwd_t(_p(gu), _p(dh), _p(dgu), _p(dguT), M, I2 // 2, _stream()), "mmu_swiglu_bwd_t")
 
 
 def colsum_nparts(M):

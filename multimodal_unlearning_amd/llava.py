@@ -423,6 +423,16 @@ class LlavaHIP(nn.Module):
         for n, t in self.wT.items():
             hip.transpose(self.w[n], t)
 
+    def _use_t(self, M):
+        return self.transposed_wgrad and not self.lora and M % 8 == 0 and M >= self.transposed_wgrad_min_m
+
+    def _wgrad_t(self, dy, dyT, xT, gname):
+        """g[gname] += dy^T x given x^T (and optionally dy^T) already in the NT layout."""
+        if dyT is None:
+            dyT = torch.empty(dy.shape[1], dy.shape[0], device=dy.device, dtype=BF)
+            hip.transpose(dy, dyT)
+        return hip.gemm(hip.NT, dyT, xT, self.g[gname], accumulate=True)
+
     def _wgrad(self, dy, x, gname):
         """g[gname] += dy^T x  (dW of y = x W^T; reduction over tokens).  Token-major operands are reduction-MAJOR
         for this product; measured on MI355X the LDS-DMA GEMM streams reduction-contiguous operands from HBM ~35 %
@@ -637,10 +647,17 @@ class LlavaHIP(nn.Module):
 
         stop_layer = saved.get("stop_layer")
         dy = torch.empty(M, dt, device=dev, dtype=BF)
+        use_t = self._use_t(M)
+        yT = torch.empty(dt, M, device=dev, dtype=BF) if use_t else None
         if stop_layer is None:
             h, rstdf = saved["final"]
-            hip.rmsnorm_fwd(h, w["text.norm.weight"], y, None, t.rms_norm_eps)
-            self._lin_bwd("lm_head.weight", dlog, y, dy)
+            if use_t:
+                hip.rmsnorm_apply_t(h, w["text.norm.weight"], rstdf, yT)
+                self._wgrad_t(dlog, None, yT, "lm_head.weight")
+                self._dgrad(dlog, "lm_head.weight", dy)
+            else:
+                hip.rmsnorm_fwd(h, w["text.norm.weight"], y, None, t.rms_norm_eps)
+                self._lin_bwd("lm_head.weight", dlog, y, dy)
             dh = torch.empty(M, dt, device=dev, dtype=BF)
             hip.rmsnorm_bwd(dy, h, w["text.norm.weight"], rstdf, None, dh, dw_part, g.get("text.norm.weight"), True)
             top = t.num_layers - 1
@@ -658,15 +675,29 @@ class LlavaHIP(nn.Module):
             hin, rstd1, qkv, a, lse, h2, rstd2, gu = layers[i]
             layers[i] = None
             # MLP
-            act = torch.empty(M, I, device=dev, dtype=BF)
-            hip.swiglu_fwd(gu, act)
             dact = torch.empty(M, I, device=dev, dtype=BF)
-            self._lin_bwd(p + "down.weight", dh, act, dact)
             dgu = torch.empty(M, 2 * I, device=dev, dtype=BF)
-            hip.swiglu_bwd(gu, dact, dgu)
-            del act, dact, gu
-            hip.rmsnorm_fwd(h2, w[p + "post_norm.weight"], y, None, t.rms_norm_eps)
-            self._lin_bwd(p + "gate_up.weight", dgu, y, dy)
+            if use_t:  # wgrad operands come out of their producers already transposed
+                actT = torch.empty(I, M, device=dev, dtype=BF)
+                hip.swiglu_fwd_t(gu, actT)
+                self._wgrad_t(dh, None, actT, p + "down.weight")
+                self._dgrad(dh, p + "down.weight", dact)
+                del actT
+                dguT = torch.empty(2 * I, M, device=dev, dtype=BF)
+                hip.swiglu_bwd_t(gu, dact, dgu, dguT)
+                del dact, gu
+                hip.rmsnorm_apply_t(h2, w[p + "post_norm.weight"], rstd2, yT)
+                self._wgrad_t(dgu, dguT, yT, p + "gate_up.weight")
+                self._dgrad(dgu, p + "gate_up.weight", dy)
+                del dguT
+            else:
+                act = torch.empty(M, I, device=dev, dtype=BF)
+                hip.swiglu_fwd(gu, act)
+                self._lin_bwd(p + "down.weight", dh, act, dact)
+                hip.swiglu_bwd(gu, dact, dgu)
+                del act, dact, gu
+                hip.rmsnorm_fwd(h2, w[p + "post_norm.weight"], y, None, t.rms_norm_eps)
+                self._lin_bwd(p + "gate_up.weight", dgu, y, dy)
             del dgu
             dh2 = torch.empty(M, dt, device=dev, dtype=BF)
             hip.rmsnorm_bwd(dy, h2, w[p + "post_norm.weight"], rstd2, dh, dh2, dw_part, g.get(p + "post_norm.weight"),
@@ -679,8 +710,13 @@ class LlavaHIP(nn.Module):
                          dqkv[:, :dt], dqkv[:, dt:2 * dt], dqkv[:, 2 * dt:], B, S, H, D, scale, True)
             hip.rope(dqkv, saved["pos"], self._cos, self._sin, H, H, D, dt, inverse=True)
             del qkv, a
-            hip.rmsnorm_fwd(hin, w[p + "input_norm.weight"], y, None, t.rms_norm_eps)
-            self._lin_bwd(p + "qkv.weight", dqkv, y, dy)
+            if use_t:
+                hip.rmsnorm_apply_t(hin, w[p + "input_norm.weight"], rstd1, yT)
+                self._wgrad_t(dqkv, None, yT, p + "qkv.weight")
+                self._dgrad(dqkv, p + "qkv.weight", dy)
+            else:
+                hip.rmsnorm_fwd(hin, w[p + "input_norm.weight"], y, None, t.rms_norm_eps)
+                self._lin_bwd(p + "qkv.weight", dqkv, y, dy)
             del dqkv
             dh = da  # overwrite: da is dead after attn_bwd
             hip.rmsnorm_bwd(dy, hin, w[p + "input_norm.weight"], rstd1, dh2, dh, dw_part,

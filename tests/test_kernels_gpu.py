@@ -516,3 +516,29 @@ def test_gemm_fused_lowrank_update(dev, tile, kl):
     res = _rand_int((M, N), dev, seed=5)
     hip.gemm(hip.NT, x, w, out, resid=res, lora_u=u, lora_b=bl)
     assert torch.equal(out, (ref.float() + res.float()).to(BF))
+
+
+def test_fused_transposed_producers(dev):
+    """SwiGLU / RMSNorm-apply / SwiGLU-backward with transposed outputs == the plain kernels followed by a transpose."""
+    M, I, d = 200, 344, 256
+    gu = _randn((M, 2 * I), dev, 2.0, 1)
+    act = torch.empty(M, I, device=dev, dtype=BF)
+    hip.swiglu_fwd(gu, act)
+    actT = torch.full((I, M), 9.0, device=dev, dtype=BF)
+    hip.swiglu_fwd_t(gu, actT)
+    assert torch.equal(actT, act.t().contiguous())
+    dh = _randn((M, I), dev, 1.0, 2)
+    dgu = torch.empty_like(gu)
+    hip.swiglu_bwd(gu, dh, dgu)
+    dgu2 = torch.empty_like(gu)
+    dguT = torch.empty(2 * I, M, device=dev, dtype=BF)
+    hip.swiglu_bwd_t(gu, dh, dgu2, dguT)
+    assert torch.equal(dgu2, dgu) and torch.equal(dguT, dgu.t().contiguous())
+    x = _randn((M, d), dev, 2.0, 3)
+    w = (1 + 0.1 * torch.randn(d, generator=torch.Generator().manual_seed(4))).to(dev).to(BF)
+    y = torch.empty_like(x)
+    rstd = torch.empty(M, device=dev, dtype=torch.float32)
+    hip.rmsnorm_fwd(x, w, y, rstd, 1e-5)
+    yT = torch.empty(d, M, device=dev, dtype=BF)
+    hip.rmsnorm_apply_t(x, w, rstd, yT)
+    assert torch.equal(yT, y.t().contiguous())
