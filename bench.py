@@ -166,7 +166,8 @@ def main():
     ap.add_argument("--micro-batch", type=int, default=15,
                     help="forget+retain pairs per GPU per micro-batch; 15 pairs = 30 sequences = 32640 tokens = 127.5 "
                          "256-row GEMM tiles -> whole rounds on 256 CUs, ~210 GB of the 288 GB HBM")
-    ap.add_argument("--grad-accum", type=int, default=1, help="micro-batches per optimiser step")
+    ap.add_argument("--grad-accum", type=int, default=4,
+                    help="micro-batches per optimiser step (reference default, config/mm/forget.yaml:15)")
     ap.add_argument("--model", default="7b", choices=["7b", "13b", "tiny"])
     ap.add_argument("--loss", default="grad_diff_forget_ce_retain_ce")
     ap.add_argument("--layers", type=int, default=0, help="debug: override decoder depth (invalidates the metric)")

@@ -51,41 +51,38 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16* __restrict
     }
 }
 
-// Backward: g = dy*w ; xh = x*rstd ; dx = rstd*(g - xh*mean(g*xh)) (+ dres) ; dw_partial[blk] += dy*xh.
-// Grid-stride over rows; each wave keeps its column partial sums in registers, the 4 waves of a block
-// are combined through LDS, and one fp32 partial row per block goes to `dw_part` [gridDim.x][d].
-template <int MAXCH>
+// Backward: g = dy*w ; xh = x*rstd ; dx = rstd*(g - xh*mean(g*xh)) (+ dres) ; dw_partial[blk] += dy*bf16(xh).
+// One 256-thread BLOCK per row (grid-stride over rows): a thread owns NCH fixed 8-column chunks, so the row fits in
+// ~70 registers (8 waves/SIMD hide the HBM latency), the row dot product is one block reduction, and the weight-
+// gradient partial sums stay in the owning thread's registers for the whole sweep: one fp32 partial row per block
+// goes to `dw_part` [gridDim.x][d] with no LDS reduction.
+template <int NCH>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x,
                                                           const bf16* __restrict__ w, const float* __restrict__ rstd,
                                                           const bf16* __restrict__ dres, bf16* __restrict__ dx,
                                                           float* __restrict__ dw_part, int M, int d) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* red = reinterpret_cast<float*>(smem_raw);  // [4][d]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ float scratch[4];
     const int nch = d >> 3;
-    float dwacc[MAXCH][8];
+    float dwacc[NCH][8], wv[NCH][8];
 #pragma unroll
-    for (int c = 0; c < MAXCH; ++c)
+    for (int c = 0; c < NCH; ++c) {
+        const int ch = c * 256 + threadIdx.x;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) dwacc[c][j] = 0.f;
-    float wv[MAXCH][8];
-#pragma unroll
-    for (int c = 0; c < MAXCH; ++c) {
-        const int ch = c * 64 + lane;
+        for (int j = 0; j < 8; ++j) { dwacc[c][j] = 0.f; wv[c][j] = 0.f; }
         if (ch < nch) {
             const bf16x8 t = *reinterpret_cast<const bf16x8*>(w + ch * 8);
 #pragma unroll
             for (int j = 0; j < 8; ++j) wv[c][j] = bf2f(t[j]);
         }
     }
-    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+    for (int row = blockIdx.x; row < M; row += gridDim.x) {
         const float rs = rstd[row];
         const size_t off = (size_t)row * d;
-        float g[MAXCH][8], xh[MAXCH][8];
+        float g[NCH][8], xh[NCH][8];
         float dot = 0.f;
 #pragma unroll
-        for (int c = 0; c < MAXCH; ++c) {
-            const int ch = c * 64 + lane;
+        for (int c = 0; c < NCH; ++c) {
+            const int ch = c * 256 + threadIdx.x;
             if (ch < nch) {
                 const bf16x8 tdy = *reinterpret_cast<const bf16x8*>(dy + off + ch * 8);
                 const bf16x8 tx = *reinterpret_cast<const bf16x8*>(x + off + ch * 8);
@@ -95,14 +92,14 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16* __restrict
                     xh[c][j] = bf2f(tx[j]) * rs;
                     g[c][j] = dyv * wv[c][j];
                     dot += g[c][j] * xh[c][j];
-                    dwacc[c][j] += dyv * round_bf16((xh[c][j]));
+                    dwacc[c][j] += dyv * round_bf16(xh[c][j]);
                 }
             }
         }
-        dot = wave_sum(dot) / (float)d;
+        dot = block_sum<4>(dot, scratch) / (float)d;
 #pragma unroll
-        for (int c = 0; c < MAXCH; ++c) {
-            const int ch = c * 64 + lane;
+        for (int c = 0; c < NCH; ++c) {
+            const int ch = c * 256 + threadIdx.x;
             if (ch < nch) {
                 bf16x8 o;
                 if (dres) {
@@ -118,16 +115,14 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16* __restrict
         }
     }
 #pragma unroll
-    for (int c = 0; c < MAXCH; ++c) {
-        const int ch = c * 64 + lane;
+    for (int c = 0; c < NCH; ++c) {
+        const int ch = c * 256 + threadIdx.x;
         if (ch < nch) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) red[wave * d + ch * 8 + j] = dwacc[c][j];
+            float* dst = dw_part + (size_t)blockIdx.x * d + ch * 8;
+            *reinterpret_cast<f32x4*>(dst) = f32x4{dwacc[c][0], dwacc[c][1], dwacc[c][2], dwacc[c][3]};
+            *reinterpret_cast<f32x4*>(dst + 4) = f32x4{dwacc[c][4], dwacc[c][5], dwacc[c][6], dwacc[c][7]};
         }
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < d; i += 256)
-        dw_part[(size_t)blockIdx.x * d + i] = red[i] + red[d + i] + red[2 * d + i] + red[3 * d + i];
 }
 
 // dst[j] (+)= sum_p part[p][j]  (column reduce of the per-block partials; bf16 destination)
@@ -621,29 +616,18 @@ extern "C" int mmu_rmsnorm_fwd(const void* x, const void* w, void* y, float* rst
 
 // dw_part must hold mmu_rmsnorm_bwd_nparts(M) * d floats.
 extern "C" int mmu_rmsnorm_bwd_nparts(int M) {
-    int g = (M + 3) / 4;
-    return g > 256 ? 256 : (g < 1 ? 1 : g);
+    return M > 1024 ? 1024 : (M < 1 ? 1 : M);
 }
 
 extern "C" int mmu_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres,
                                void* dx, float* dw_part, void* dw, int accumulate_dw, int M, int d, void* stream) {
-    if (M <= 0 || (d & 7)) return -1;
+    if (M <= 0 || (d & 7) || d > 8192) return -1;
     hipStream_t s = (hipStream_t)stream;
     const int grid = mmu_rmsnorm_bwd_nparts(M);
-    const size_t lds = (size_t)4 * d * sizeof(float);
-#define CALL(N)                                                                                                   \
-    do {                                                                                                          \
-        static bool cfg = false;                                                                                  \
-        if (!cfg) {                                                                                               \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rmsnorm_bwd_kernel<N>),              \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 512 * N * 4);      \
-            if (e != hipSuccess) return (int)e;                                                                   \
-            cfg = true;                                                                                           \
-        }                                                                                                         \
-        hipLaunchKernelGGL(rmsnorm_bwd_kernel<N>, dim3(grid), dim3(256), lds, s, (const bf16*)dy, (const bf16*)x, \
-                           (const bf16*)w, rstd, (const bf16*)dres, (bf16*)dx, dw_part, M, d);                    \
-    } while (0)
-    MMU_MAXCH_DISPATCH(d, CALL);
+#define CALL(N)                                                                                              \
+    hipLaunchKernelGGL(rmsnorm_bwd_kernel<N>, dim3(grid), dim3(256), 0, s, (const bf16*)dy, (const bf16*)x,  \
+                       (const bf16*)w, rstd, (const bf16*)dres, (bf16*)dx, dw_part, M, d)
+    if (d <= 2048) { CALL(1); } else if (d <= 4096) { CALL(2); } else if (d <= 6144) { CALL(3); } else { CALL(4); }
 #undef CALL
     MMU_CHECK_LAUNCH();
     if (dw) {
