@@ -173,6 +173,7 @@ def main():
     ap.add_argument("--layers", type=int, default=0, help="debug: override decoder depth (invalidates the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fuse", action="store_true")
+    ap.add_argument("--no-wt", action="store_true", help="do not keep resident W^T copies (saves one weight copy of HBM)")
     ap.add_argument("--lora-r", type=int, default=0, help="LoRA rank (0 = full fine-tuning); BASELINE config 2 uses 8")
     ap.add_argument("--lora-alpha", type=float, default=32.0)
     args = ap.parse_args()
@@ -204,7 +205,8 @@ def main():
     tr = MMTrainerForgetting(model=model, forget_loss=args.loss, teacher_model=teacher, loss_beta=1.0, l1_lambda=0.0,
                              l0_lambda=0.0, l_norm_from="zero", loss_args={"fuse_pairs": not args.no_fuse})
     fcfg = ForgetConfig(batch_size=args.micro_batch, gradient_accumulation_steps=args.grad_accum)
-    eng = ForgetEngine(model, tr, fcfg, total_steps=args.steps + args.warmup + 1, warmup_steps=1)
+    eng = ForgetEngine(model, tr, fcfg, total_steps=args.steps + args.warmup + 1, warmup_steps=1,
+                       transposed_weights=not args.no_wt)
 
     B, GA = args.micro_batch, args.grad_accum
     if args.model == "tiny":
@@ -243,8 +245,17 @@ def main():
     if rank == 0:
         samples = world * B * GA * args.steps
         value = samples / elapsed
-        paired = args.loss.lower() not in ("grad_ascent", "retain_ft")
+        lt = args.loss.lower()
+        paired = lt not in ("grad_ascent", "retain_ft", "npo")
         fps = flops_per_sample(cfg, S, paired=paired, lora=bool(args.lora_r))
+        # teacher forwards (no grad): npo 1, kl 1, scrub 2, grad_diff_*_kl 1 per kl side
+        t_fwd = {"npo": 1, "kl": 1, "scrub": 2, "llmu": 1}.get(lt, lt.count("_kl") if lt.startswith("grad_diff") else 0)
+        if t_fwd:
+            # forward FLOPs of one sequence = fb_full - 2*(dec+proj) ; recover it from the two closed forms
+            full = flops_per_sample(cfg, S, paired=False, lora=False)
+            lo = flops_per_sample(cfg, S, paired=False, lora=True)
+            one_fwd = 2 * lo - full
+            fps += t_fwd * one_fwd
         f, t, n, by = timer.summary()
         out = {
             "metric": "forget-step samples/sec (img+text pairs) LLaVA-1.5-7B grad_diff",
