@@ -74,7 +74,7 @@ class GemmTimer:
             else:
                 k, m = A.shape
                 n = B.shape[1]
-            self.records.append((layout, m, n, k, e0, e1))
+            self.records.append((layout, m, n, k, e0, e1, bool(kw.get("accumulate")), kw.get("resid") is not None))
             return r
 
         self.hip.gemm = timed
@@ -87,9 +87,12 @@ class GemmTimer:
         torch.cuda.synchronize()
         tot_f = tot_t = 0.0
         by = {}
-        for layout, m, n, k, e0, e1 in self.records:
+        self.alg_bytes = 0.0
+        for layout, m, n, k, e0, e1, acc, res in self.records:
             ms = e0.elapsed_time(e1)
             f = 2.0 * m * n * k
+            # algorithmic HBM bytes of one launch: read A and B once, write C once (+ read C / residual once)
+            self.alg_bytes += 2.0 * (m * k + n * k + m * n * (1 + int(acc) + int(res)))
             tot_f += f
             tot_t += ms * 1e-3
             key = ("NT", "NN", "TN")[layout]
@@ -257,6 +260,15 @@ def main():
             one_fwd = 2 * lo - full
             fps += t_fwd * one_fwd
         f, t, n, by = timer.summary()
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_gemm_traffic.json")
+        if os.path.exists(pmc) and args.model == "7b" and args.loss == "grad_diff_forget_ce_retain_ce" and not args.lora_r \
+                and args.micro_batch == 15:
+            # HBM-side bytes per GEMM launch from rocprofv3 PMC passes of this same workload (FETCH_SIZE x2 on gfx950 +
+            # WRITE_SIZE, separate passes; counts L2 misses incl. Infinity-Cache hits) — collected offline by
+            # tools/pmc_bench_traffic.sh, because PMC collection cannot run inside the timed process
+            pj = json.load(open(pmc))
+            traffic, traffic_src = round(pj["traffic_bytes_per_launch"]), "profiles/r01_pmc_gemm_traffic.json"
         out = {
             "metric": "forget-step samples/sec (img+text pairs) LLaVA-1.5-7B grad_diff",
             "value": round(value, 4), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -270,7 +282,9 @@ def main():
             "step_tflops_per_gpu": round(value * fps / world / 1e12, 1),
             "step_frac_of_mfma_peak": round(value * fps / world / PEAK_BF16, 4),
             "roofline": {"bound": "mfma", "achieved": round(f / t / 1e12, 1), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
-                         "frac": round(f / t / PEAK_BF16, 4), "traffic": None, "kernel": "gemm_bf16_kernel (all layouts)",
+                         "frac": round(f / t / PEAK_BF16, 4), "traffic": traffic, "traffic_unit": "bytes per launch",
+                         "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(timer.alg_bytes / n),
+                         "kernel": "g256::gemm256_kernel / gemm_bf16_kernel (all layouts)",
                          "launches": n, "avg_launch_us": round(t / n * 1e6, 1),
                          "gemm_share_of_step": round(t / (elapsed / args.steps), 3), "by_layout": by},
         }
