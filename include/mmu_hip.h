@@ -33,6 +33,14 @@ int mmu_gemm_bf16(int layout, const void* A, const void* B, void* C, const void*
 int mmu_gemm_bf16_lora(int layout, const void* A, const void* B, void* C, const void* bias, const void* resid,
                        int M, int N, int K, int lda, int ldb, int ldc, int ldr, int act, int accumulate,
                        const void* lora_u, const void* lora_b, int lora_k, void* stream);
+/* 1 if mmu_gemm_bf16 would use the 256x256 kernel for this shape. */
+int mmu_gemm_uses_256(int M, int N, int K);
+/* y = x W^T (+LoRA) with apply_rotary_pos_emb (modeling_llama.py rotate-half, head_dim 128) applied to columns
+ * [0, rope_cols) in the epilogue — the q|k part of the fused qkv projection.  rope_pos [M] int32, tables [n_pos][64]
+ * bf16.  Returns -2 if the shape would not run on the 256x256 kernel (caller: mmu_gemm_bf16 + mmu_rope). */
+int mmu_gemm_bf16_rope(int layout, const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                       const void* lora_u, const void* lora_b, int lora_k, const int* rope_pos, const void* rope_cos,
+                       const void* rope_sin, int rope_cols, void* stream);
 /* Tile configuration override (A/B tests, tuning): 0 = heuristic, 128 = 128x128x64 4-wave kernel,
  * 256 = 256x256x64 8-wave 8-phase kernel.  Process-wide. */
 int mmu_gemm_set_tile(int tile);
@@ -50,6 +58,12 @@ int mmu_attn_fwd(const void* q, const void* k, const void* v, int ld, void* o, i
 int mmu_attn_bwd(const void* q, const void* k, const void* v, int ld, const void* o, int ldo, const float* lse,
                  const int* kmask, const void* dout, int lddo, float* delta, void* dq, void* dk, void* dv,
                  int ldg, int B, int S, int H, int head_dim, float scale, int causal, void* stream);
+
+/* mmu_attn_bwd with the inverse RoPE rotation fused into the dq / dk stores (gradient w.r.t. the un-rotated q, k). */
+int mmu_attn_bwd_rope(const void* q, const void* k, const void* v, int ld, const void* o, int ldo, const float* lse,
+                      const int* kmask, const void* dout, int lddo, float* delta, void* dq, void* dk, void* dv, int ldg,
+                      int B, int S, int H, int head_dim, float scale, int causal, const int* rope_pos,
+                      const void* rope_cos, const void* rope_sin, void* stream);
 
 /* ---- Norms (LlamaRMSNorm / CLIP LayerNorm; SURVEY §8a K2,K7) ---- */
 int mmu_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int M, int d, float eps, void* stream);

@@ -111,6 +111,40 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& v, int s) {
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// Store one gradient row fragment held as acc[dt][4g+j] <-> d = dt*32 + 8g + 4*hl + j (D = 128), optionally applying
+// the transpose rotation of RoPE to the (d, d+64) pairs = (dt, dt+2): same arithmetic as rope_kernel(inverse=1) on the
+// bf16-rounded gradient.
+__device__ __forceinline__ void store_grad_row(bf16* dst, const f32x16 (&acc)[4], int hl, const bf16* cos_row,
+                                               const bf16* sin_row) {
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int d = dt * 32 + 8 * g + 4 * hl;  // < 64
+            bf16x4 t, u;
+            if (cos_row) {
+                const bf16x4 c4 = *reinterpret_cast<const bf16x4*>(cos_row + d);
+                const bf16x4 s4 = *reinterpret_cast<const bf16x4*>(sin_row + d);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float a = round_bf16(acc[dt][4 * g + j]), b = round_bf16(acc[dt + 2][4 * g + j]);
+                    const float cf = bf2f(c4[j]), sf = bf2f(s4[j]);
+                    t[j] = f2bf(round_bf16(a * cf) + round_bf16(b * sf));
+                    u[j] = f2bf(round_bf16(b * cf) + round_bf16(-a * sf));
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    t[j] = f2bf(acc[dt][4 * g + j]);
+                    u[j] = f2bf(acc[dt + 2][4 * g + j]);
+                }
+            }
+            *reinterpret_cast<bf16x4*>(dst + d) = t;
+            *reinterpret_cast<bf16x4*>(dst + d + 64) = u;
+        }
+}
+
+
 struct AttnArgs {
     const bf16* q;
     const bf16* k;
@@ -130,6 +164,10 @@ struct AttnArgs {
     bf16* dk;
     bf16* dv;
     int ldg;  // row stride of dq/dk/dv
+    // optional fused inverse RoPE on the dq / dk stores (head_dim 128): positions [B*S], tables [n_pos][64] bf16
+    const int* rope_pos;
+    const bf16* rope_cos;
+    const bf16* rope_sin;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -434,15 +472,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     }
     if (qvalid) {
         bf16* op = a.dq + (rowbase + qrow) * a.ldg + hh * D;
-#pragma unroll
-        for (int dt = 0; dt < NDT; ++dt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                bf16x4 t;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) t[j] = f2bf(acc[dt][4 * g + j]);
-                *reinterpret_cast<bf16x4*>(op + dt * 32 + 8 * g + 4 * hl) = t;
-            }
+        const bf16* cr = nullptr;
+        const bf16* sr = nullptr;
+        if (a.rope_pos) {
+            const int pos = a.rope_pos[rowbase + qrow];
+            cr = a.rope_cos + (size_t)pos * 64;
+            sr = a.rope_sin + (size_t)pos * 64;
+        }
+        store_grad_row(op, acc, hl, cr, sr);
     }
 }
 
@@ -636,17 +673,19 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                bf16x4 t, u;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int r = 4 * g + j;
-                    t[j] = f2bf(dk[dt][r] + slab[(dt * 16 + r) * 64 + lane]);
-                    u[j] = f2bf(dv[dt][r] + slab[(64 + dt * 16 + r) * 64 + lane]);
-                }
-                *reinterpret_cast<bf16x4*>(dkp + dt * 32 + 8 * g + 4 * hl) = t;
-                *reinterpret_cast<bf16x4*>(dvp + dt * 32 + 8 * g + 4 * hl) = u;
+            for (int r = 0; r < 16; ++r) {
+                dk[dt][r] += slab[(dt * 16 + r) * 64 + lane];
+                dv[dt][r] += slab[(64 + dt * 16 + r) * 64 + lane];
             }
+        const bf16* cr = nullptr;
+        const bf16* sr = nullptr;
+        if (a.rope_pos) {
+            const int pos = a.rope_pos[rowbase + key];
+            cr = a.rope_cos + (size_t)pos * 64;
+            sr = a.rope_sin + (size_t)pos * 64;
+        }
+        store_grad_row(dkp, dk, hl, cr, sr);
+        store_grad_row(dvp, dv, hl, nullptr, nullptr);
     }
 }
 
@@ -721,11 +760,30 @@ extern "C" int mmu_attn_fwd(const void* q, const void* k, const void* v, int ld,
 
 // Backward (head_dim 128 only): needs q,k,v,o,lse of the forward plus dout; writes dq,dk,dv (row stride ldg,
 // head h at column h*head_dim of each pointer) and uses delta [B][H][S] fp32 as workspace.
+extern "C" int mmu_attn_bwd_rope(const void* q, const void* k, const void* v, int ld, const void* o, int ldo,
+                                 const float* lse, const int* kmask, const void* dout, int lddo, float* delta,
+                                 void* dq, void* dk, void* dv, int ldg, int B, int S, int H, int head_dim, float scale,
+                                 int causal, const int* rope_pos, const void* rope_cos, const void* rope_sin,
+                                 void* stream);
+
 extern "C" int mmu_attn_bwd(const void* q, const void* k, const void* v, int ld, const void* o, int ldo,
                             const float* lse, const int* kmask, const void* dout, int lddo, float* delta, void* dq,
                             void* dk, void* dv, int ldg, int B, int S, int H, int head_dim, float scale, int causal,
                             void* stream) {
+    return mmu_attn_bwd_rope(q, k, v, ld, o, ldo, lse, kmask, dout, lddo, delta, dq, dk, dv, ldg, B, S, H, head_dim,
+                             scale, causal, nullptr, nullptr, nullptr, stream);
+}
+
+// mmu_attn_bwd with the inverse RoPE rotation (gradient w.r.t. the un-rotated q, k) fused into the dq / dk stores;
+// rope_pos [B*S] int32, rope_cos / rope_sin [n_pos][64] bf16 (all three NULL: plain mmu_attn_bwd).
+extern "C" int mmu_attn_bwd_rope(const void* q, const void* k, const void* v, int ld, const void* o, int ldo,
+                                 const float* lse, const int* kmask, const void* dout, int lddo, float* delta,
+                                 void* dq, void* dk, void* dv, int ldg, int B, int S, int H, int head_dim, float scale,
+                                 int causal, const int* rope_pos, const void* rope_cos, const void* rope_sin,
+                                 void* stream) {
     AttnArgs a = {};
+    a.rope_pos = rope_pos; a.rope_cos = (const bf16*)rope_cos; a.rope_sin = (const bf16*)rope_sin;
+    if (rope_pos && (!rope_cos || !rope_sin)) return -1;
     a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.ld = ld;
     a.o = (bf16*)const_cast<void*>(o); a.ldo = ldo; a.lse = const_cast<float*>(lse); a.kmask = kmask;
     a.B = B; a.S = S; a.H = H; a.scale = scale;

@@ -23,6 +23,8 @@
 // lane ends up with 4 consecutive n of one output row -> 8-byte bf16x4 stores.
 #include "common.h"
 
+struct RopeReq { const int* pos; const bf16* cos; const bf16* sin; int cols; };
+static RopeReq g_rope = {nullptr, nullptr, nullptr, 0};  // set only for the duration of mmu_gemm_bf16_rope
 static int g_force_tile = 0;  // mmu_gemm_set_tile
 static int g_group_m = 0;     // mmu_gemm_set_group_m
 namespace {
@@ -46,6 +48,12 @@ struct GemmArgs {
     const bf16* lora_u;
     const bf16* lora_b;
     int lora_k;
+    // fused RoPE (256^2 kernel, plain epilogue only): columns n < rope_cols are rotated per 128-wide head with the
+    // rotate-half convention, position rope_pos[m], tables [n_pos][64] bf16 (apply_rotary_pos_emb after the q/k Linear)
+    const int* rope_pos;
+    const bf16* rope_cos;
+    const bf16* rope_sin;
+    int rope_cols;
 };
 
 __device__ __forceinline__ int swzT(int k) { return ((k & 3) << 1) | (((k >> 3) & 1) << 3); }
@@ -509,13 +517,27 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             const int m = m0 + wm * 128 + a * 64 + mt * 16 + (lane & 15);
+            const int pos = (EPI == 0 && p.rope_pos && m < p.M) ? p.rope_pos[m] : 0;
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
+            for (int nt = 0; nt < 2; ++nt) {
+                // b = 0 / 1 are columns c and c + 64 of the same 128-wide group: the two halves of a RoPE pair
+                const int cih = (wn & 1) * 32 + nt * 16 + 4 * (lane >> 4);  // column inside the 128-wide group (< 64)
+                const int n = n0 + (wn >> 1) * 128 + cih;
+                f32x4 v0 = acc[a][0][nt][mt], v1 = acc[a][1][nt][mt];
+                if (EPI == 0 && p.rope_pos && n < p.rope_cols && m < p.M) {
+                    const bf16x4 c4 = *reinterpret_cast<const bf16x4*>(p.rope_cos + (size_t)pos * 64 + cih);
+                    const bf16x4 s4 = *reinterpret_cast<const bf16x4*>(p.rope_sin + (size_t)pos * 64 + cih);
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    const int n = n0 + (wn >> 1) * 128 + b * 64 + (wn & 1) * 32 + nt * 16 + 4 * (lane >> 4);
-                    epi_store<EPI>(p, m, n, acc[a][b][nt][mt]);
+                    for (int j = 0; j < 4; ++j) {
+                        const float x1 = round_bf16(v0[j]), x2 = round_bf16(v1[j]);
+                        const float cf = bf2f(c4[j]), sf = bf2f(s4[j]);
+                        v0[j] = round_bf16(x1 * cf) + round_bf16(-x2 * sf);
+                        v1[j] = round_bf16(x2 * cf) + round_bf16(x1 * sf);
+                    }
                 }
+                epi_store<EPI>(p, m, n, v0);
+                epi_store<EPI>(p, m, n + 64, v1);
+            }
         }
 #undef G256_BAR
 #undef G256_LGKM8
@@ -575,6 +597,10 @@ static bool pick_256(int M, int N, int K) {
 extern "C" int mmu_gemm_bf16_lora(int layout, const void* A, const void* B, void* C, const void* bias,
                                   const void* resid, int M, int N, int K, int lda, int ldb, int ldc, int ldr, int act,
                                   int accumulate, const void* lora_u, const void* lora_b, int lora_k, void* stream);
+extern "C" int mmu_gemm_bf16_rope(int layout, const void* A, const void* B, void* C, int M, int N, int K, int lda,
+                                  int ldb, int ldc, const void* lora_u, const void* lora_b, int lora_k,
+                                  const int* rope_pos, const void* rope_cos, const void* rope_sin, int rope_cols,
+                                  void* stream);
 
 extern "C" int mmu_gemm_bf16(int layout, const void* A, const void* B, void* C, const void* bias, const void* resid,
                              int M, int N, int K, int lda, int ldb, int ldc, int ldr, int act, int accumulate,
@@ -603,6 +629,8 @@ extern "C" int mmu_gemm_bf16_lora(int layout, const void* A, const void* B, void
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldr = ldr;
     a.act = act; a.accumulate = accumulate;
     a.lora_u = (const bf16*)lora_u; a.lora_b = (const bf16*)lora_b; a.lora_k = lora_k;
+    a.rope_pos = g_rope.pos; a.rope_cos = g_rope.cos; a.rope_sin = g_rope.sin; a.rope_cols = g_rope.cols;
+    if (a.rope_pos && !pick_256(M, N, K)) return -2;  // fused RoPE exists in the 256^2 kernel only
     a.tiles_m = (M + BM - 1) / BM; a.tiles_n = (N + BN - 1) / BN;
     hipStream_t s = (hipStream_t)stream;
     if (pick_256(M, N, K)) {
@@ -633,4 +661,22 @@ extern "C" int mmu_gemm_set_group_m(int group_m) {
     if (group_m < 0 || group_m > 64) return -1;
     g_group_m = group_m;
     return 0;
+}
+
+// 1 if mmu_gemm_bf16 would run the 256x256 kernel for this shape (the only one with the fused RoPE epilogue).
+extern "C" int mmu_gemm_uses_256(int M, int N, int K) { return pick_256(M, N, K) ? 1 : 0; }
+
+// y = x W^T (+ LoRA) with RoPE applied to columns [0, rope_cols) in the epilogue (q|k part of the fused qkv
+// projection, head_dim 128, N % 256 alignment of heads).  Returns -2 when the shape would not run on the 256^2
+// kernel: the caller then issues mmu_gemm_bf16 + mmu_rope.
+extern "C" int mmu_gemm_bf16_rope(int layout, const void* A, const void* B, void* C, int M, int N, int K, int lda,
+                                  int ldb, int ldc, const void* lora_u, const void* lora_b, int lora_k,
+                                  const int* rope_pos, const void* rope_cos, const void* rope_sin, int rope_cols,
+                                  void* stream) {
+    if (!rope_pos || !rope_cos || !rope_sin || (rope_cols & 127) || rope_cols > N) return -1;
+    g_rope = {rope_pos, (const bf16*)rope_cos, (const bf16*)rope_sin, rope_cols};
+    const int rc = mmu_gemm_bf16_lora(layout, A, B, C, nullptr, nullptr, M, N, K, lda, ldb, ldc, 0, 0, 0, lora_u, lora_b,
+                                      lora_k, stream);
+    g_rope = {nullptr, nullptr, nullptr, 0};
+    return rc;
 }

@@ -22,11 +22,15 @@ SIGNATURES = {
     "mmu_abi_version": [],
     "mmu_gemm_bf16": [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "mmu_gemm_bf16_lora": [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp],
+    "mmu_gemm_uses_256": [_i, _i, _i],
+    "mmu_gemm_bf16_rope": [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp],
     "mmu_gemm_set_tile": [_i],
     "mmu_gemm_set_group_m": [_i],
     "mmu_attn_fwd": [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp],
     "mmu_attn_bwd": [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i,
                      _vp],
+    "mmu_attn_bwd_rope": [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i,
+                          _vp, _vp, _vp, _vp],
     "mmu_rmsnorm_fwd": [_vp, _vp, _vp, _vp, _i, _i, _f, _vp],
     "mmu_rmsnorm_bwd_nparts": [_i],
     "mmu_rmsnorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
@@ -143,6 +147,21 @@ def gemm(layout: int, A, B, out, *, bias=None, resid=None, act=0, accumulate=Fal
     return out
 
 
+def gemm_rope(x, w, out, pos_ids, cos_t, sin_t, rope_cols, lora_u=None, lora_b=None) -> bool:
+    """out = x w^T (+LoRA) with RoPE applied to columns [0, rope_cols) in the GEMM epilogue.  Returns False (nothing
+    launched) when the shape would run on the 128^2 kernel: the caller then does gemm + rope."""
+    _bf16c(x, w, out, cos_t, sin_t, lora_u, lora_b)
+    M, K = x.shape
+    N = w.shape[0]
+    if not load().mmu_gemm_uses_256(M, N, K) or cos_t.shape[1] != 64:
+        return False
+    kl = 0 if lora_u is None else lora_u.shape[1]
+    rc = load().mmu_gemm_bf16_rope(NT, _p(x), _p(w), _p(out), M, N, K, x.stride(0), w.stride(0), out.stride(0), _p(lora_u),
+                                   _p(lora_b), kl, _p(pos_ids), _p(cos_t), _p(sin_t), rope_cols, _stream())
+    _check(rc, "mmu_gemm_bf16_rope")
+    return True
+
+
 def gemm_set_group_m(g: int):
     _check(load().mmu_gemm_set_group_m(int(g)), "mmu_gemm_set_group_m")
 
@@ -163,13 +182,15 @@ def attn_fwd(q, k, v, out, lse, kmask, B, S, H, head_dim, scale, causal):
     return out
 
 
-def attn_bwd(q, k, v, o, lse, kmask, dout, delta, dq, dk, dv, B, S, H, head_dim, scale, causal):
+def attn_bwd(q, k, v, o, lse, kmask, dout, delta, dq, dk, dv, B, S, H, head_dim, scale, causal, rope=None):
+    """rope = (pos_ids int32 [B*S], cos_t, sin_t [n_pos,64]): fuse the inverse RoPE rotation into the dq / dk stores."""
     _bf16c(q, k, v, o, dout, dq, dk, dv)
     assert dq.stride(0) == dk.stride(0) == dv.stride(0)
-    rc = load().mmu_attn_bwd(_p(q), _p(k), _p(v), q.stride(0), _p(o), o.stride(0), _p(lse), _p(kmask), _p(dout),
-                             dout.stride(0), _p(delta), _p(dq), _p(dk), _p(dv), dq.stride(0), B, S, H, head_dim,
-                             float(scale), int(causal), _stream())
-    _check(rc, "mmu_attn_bwd")
+    pos, ct, st = rope if rope is not None else (None, None, None)
+    rc = load().mmu_attn_bwd_rope(_p(q), _p(k), _p(v), q.stride(0), _p(o), o.stride(0), _p(lse), _p(kmask), _p(dout),
+                                  dout.stride(0), _p(delta), _p(dq), _p(dk), _p(dv), dq.stride(0), B, S, H, head_dim,
+                                  float(scale), int(causal), _p(pos), _p(ct), _p(st), _stream())
+    _check(rc, "mmu_attn_bwd_rope")
 
 
 # ------------------------------------------------------------------------------------------------ norms

@@ -22,6 +22,7 @@ fused in one [tokens, 3*H*D] buffer that the attention kernels index by head (no
 from __future__ import annotations
 
 import math
+import os
 from collections import OrderedDict
 from typing import Callable, Dict, Optional
 
@@ -201,6 +202,7 @@ class LlavaHIP(nn.Module):
         self._wT_flat: Optional[torch.Tensor] = None
         self.transposed_wgrad = True
         self.transposed_wgrad_min_m = 1024
+        self.fuse_rope = os.environ.get("MMU_NO_ROPE_FUSION", "0") != "1"  # A/B switch
         if params is not None:
             self.load_params(params)
         elif init == "device":
@@ -324,6 +326,20 @@ class LlavaHIP(nn.Module):
         U = torch.empty(x.shape[0], ad.kl, device=x.device, dtype=BF)
         hip.gemm(hip.NT, x, ad.A32s, U)  # s * x A^T
         return hip.gemm(hip.NT, x, self.w[wname], out, bias=bias, resid=resid, lora_u=U, lora_b=ad.BL)
+
+    def _qkv_fwd(self, wname, x, qkv, pos, H, D, dt):
+        """Fused q|k|v projection + RoPE on the q, k thirds: in the GEMM epilogue when the 256^2 kernel runs the shape
+        (head_dim 128), else GEMM followed by the in-place RoPE kernel."""
+        ad = self.lora.get(wname)
+        U = None
+        if ad is not None:
+            U = torch.empty(x.shape[0], ad.kl, device=x.device, dtype=BF)
+            hip.gemm(hip.NT, x, ad.A32s, U)
+        if D == 128 and self.fuse_rope and hip.gemm_rope(x, self.w[wname], qkv, pos, self._cos, self._sin, 2 * dt, lora_u=U,
+                                      lora_b=None if ad is None else ad.BL):
+            return
+        hip.gemm(hip.NT, x, self.w[wname], qkv, lora_u=U, lora_b=None if ad is None else ad.BL)
+        hip.rope(qkv, pos, self._cos, self._sin, H, H, D, dt)
 
     def _lin_bwd(self, wname, dy, x, dx):
         """Backward of out = x W^T (+LoRA): accumulates the weight (or adapter) gradients, writes dx if given."""
@@ -595,8 +611,7 @@ class LlavaHIP(nn.Module):
             rstd1 = torch.empty(M, device=dev, dtype=torch.float32)
             hip.rmsnorm_fwd(h, w[p + "input_norm.weight"], y, rstd1, t.rms_norm_eps)
             qkv = torch.empty(M, 3 * dt, device=dev, dtype=BF)
-            self._lin_fwd(p + "qkv.weight", y, qkv)
-            hip.rope(qkv, pos, self._cos, self._sin, H, H, D, dt)
+            self._qkv_fwd(p + "qkv.weight", y, qkv, pos, H, D, dt)
             a = torch.empty(M, dt, device=dev, dtype=BF)
             lse = torch.empty(B, H, S, device=dev, dtype=torch.float32) if save else None
             hip.attn_fwd(qkv[:, :dt], qkv[:, dt:2 * dt], qkv[:, 2 * dt:], a, lse, kmask, B, S, H, D, scale, True)
@@ -707,8 +722,10 @@ class LlavaHIP(nn.Module):
             self._lin_bwd(p + "o.weight", dh2, a, da)
             dqkv = torch.empty(M, 3 * dt, device=dev, dtype=BF)
             hip.attn_bwd(qkv[:, :dt], qkv[:, dt:2 * dt], qkv[:, 2 * dt:], a, lse, saved["kmask"], da, delta,
-                         dqkv[:, :dt], dqkv[:, dt:2 * dt], dqkv[:, 2 * dt:], B, S, H, D, scale, True)
-            hip.rope(dqkv, saved["pos"], self._cos, self._sin, H, H, D, dt, inverse=True)
+                         dqkv[:, :dt], dqkv[:, dt:2 * dt], dqkv[:, 2 * dt:], B, S, H, D, scale, True,
+                         rope=(saved["pos"], self._cos, self._sin) if self.fuse_rope else None)
+            if not self.fuse_rope:
+                hip.rope(dqkv, saved["pos"], self._cos, self._sin, H, H, D, dt, inverse=True)
             del qkv, a
             if use_t:
                 hip.rmsnorm_apply_t(hin, w[p + "input_norm.weight"], rstd1, yT)

@@ -542,3 +542,40 @@ def test_fused_transposed_producers(dev):
     yT = torch.empty(d, M, device=dev, dtype=BF)
     hip.rmsnorm_apply_t(x, w, rstd, yT)
     assert torch.equal(yT, y.t().contiguous())
+
+
+def test_fused_rope_epilogue_and_bwd_store(dev):
+    """(a) qkv GEMM with RoPE in the epilogue == GEMM then the rope kernel (bit-exact, 256^2 kernel);
+    (b) attention backward with the inverse rotation fused into the dq/dk stores == attn_bwd then rope(inverse)."""
+    import math
+    B, S, H, D = 2, 320, 2, 128
+    M, dt = B * S, H * D
+    x = _randn((M, 512), dev, 1.0, 1)
+    w = _randn((3 * dt, 512), dev, 0.05, 2)
+    pos = torch.arange(S, dtype=torch.int32, device=dev).repeat(B)
+    cos_t = torch.empty(S, D // 2, device=dev, dtype=BF)
+    sin_t = torch.empty(S, D // 2, device=dev, dtype=BF)
+    hip.rope_table(cos_t, sin_t, S, D, 10000.0)
+    hip.gemm_set_tile(256)
+    ref = torch.empty(M, 3 * dt, device=dev, dtype=BF)
+    hip.gemm(hip.NT, x, w, ref)
+    hip.rope(ref, pos, cos_t, sin_t, H, H, D, dt)
+    out = torch.empty_like(ref)
+    assert hip.gemm_rope(x, w, out, pos, cos_t, sin_t, 2 * dt)
+    assert torch.equal(out, ref)
+    # backward stores
+    qkv = ref
+    o = torch.empty(M, dt, device=dev, dtype=BF)
+    lse = torch.empty(B, H, S, device=dev, dtype=torch.float32)
+    sc = 1 / math.sqrt(D)
+    hip.attn_fwd(qkv[:, :dt], qkv[:, dt:2 * dt], qkv[:, 2 * dt:], o, lse, None, B, S, H, D, sc, True)
+    do = _randn((M, dt), dev, 1.0, 3)
+    delta = torch.empty(B, H, S, device=dev, dtype=torch.float32)
+    d1 = torch.empty(M, 3 * dt, device=dev, dtype=BF)
+    hip.attn_bwd(qkv[:, :dt], qkv[:, dt:2 * dt], qkv[:, 2 * dt:], o, lse, None, do, delta, d1[:, :dt], d1[:, dt:2 * dt],
+                 d1[:, 2 * dt:], B, S, H, D, sc, True)
+    hip.rope(d1, pos, cos_t, sin_t, H, H, D, dt, inverse=True)
+    d2 = torch.empty_like(d1)
+    hip.attn_bwd(qkv[:, :dt], qkv[:, dt:2 * dt], qkv[:, 2 * dt:], o, lse, None, do, delta, d2[:, :dt], d2[:, dt:2 * dt],
+                 d2[:, 2 * dt:], B, S, H, D, sc, True, rope=(pos, cos_t, sin_t))
+    assert torch.equal(d2, d1)
