@@ -16,6 +16,8 @@
 // LDS tiles are [rows][D] row-major, lane-linear as LDS-DMA writes them, XOR-swizzled on the per-lane
 // source address and on the reads.  D=128 (256-B rows): chunk ^= ((row&3)<<2)|((row>>2)&3), which is
 // conflict-free for both ds_read_b128 row reads and transposed reads (guide T10 image (b)).
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -225,35 +227,34 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
         }
     };
 
-    stage(0, 0);
-    for (int kb = 0; kb < nblk; ++kb) {
-        const int cur = kb & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (kb + 1 < nblk) stage(kb + 1, cur ^ 1);
-        const bool active = !CAUSAL || (kb * 64 <= q0 + 31);
-        if (active) {
-            const MMU_LDS char* kt = (const MMU_LDS char*)smem + cur * 2 * TB;
-            const MMU_LDS char* vt = kt + TB;
-            const MMU_LDS float* kbs = (const MMU_LDS float*)(smem + 4 * TB) + cur * 64;
-            f32x16 s[2];
+    // One KV block (64 keys).  MASKED = false is the fast path for blocks that need no causal / padding / tail mask:
+    // no compares, no bias loads, and exp2(fma(s, c, -m)) instead of scale + bias + subtract.
+    auto block = [&](auto MASKC, int kb, int buf) {
+        constexpr bool MASKED = decltype(MASKC)::value;
+        const MMU_LDS char* kt = (const MMU_LDS char*)smem + buf * 2 * TB;
+        const MMU_LDS char* vt = kt + TB;
+        const MMU_LDS float* kbs = (const MMU_LDS float*)(smem + 4 * TB) + buf * 64;
+        f32x16 s[2];
 #pragma unroll
-            for (int st = 0; st < 2; ++st) {
+        for (int st = 0; st < 2; ++st) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) s[st][r] = 0.f;
-                bf16x8 kf[NKS];
+            for (int r = 0; r < 16; ++r) s[st][r] = 0.f;
 #pragma unroll
-                for (int ks = 0; ks < NKS; ++ks)
-                    kf[ks] = *(const MMU_LDS bf16x8*)(kt + st * 32 * (D * 2) + fo_k.row[ks]);
-                __builtin_amdgcn_sched_barrier(0);  // the whole fragment batch is in flight before the first MFMA waits
+            for (int h4 = 0; h4 < NKS; h4 += 4) {  // fragment batches of 4: in flight before the first MFMA waits
+                bf16x8 kf[4];
 #pragma unroll
-                for (int ks = 0; ks < NKS; ++ks) s[st] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], s[st], 0, 0, 0);
+                for (int ks = 0; ks < 4; ++ks) kf[ks] = *(const MMU_LDS bf16x8*)(kt + st * 32 * (D * 2) + fo_k.row[h4 + ks]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                    s[st] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[h4 + ks], s[st], 0, 0, 0);
             }
-            // scale (log2 domain), key bias, causal mask
+        }
+        float mx = -INFINITY;
+        if (MASKED) {
             const bool diag = CAUSAL && (kb * 64 + 63 > q0);
-            float mx = -INFINITY;
 #pragma unroll
-            for (int st = 0; st < 2; ++st) {
+            for (int st = 0; st < 2; ++st)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int kl = st * 32 + 8 * g + 4 * hl;  // local key of reg 4g
@@ -266,41 +267,63 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
                         mx = fmaxf(mx, x);
                     }
                 }
+        } else {
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[st][r]);
+            mx *= c;  // c > 0: max commutes with the scale
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m, mx);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = fast_exp2(m - m_use);
+        float rs = 0.f;
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = MASKED ? fast_exp2(s[st][r] - m_use) : fast_exp2(__builtin_fmaf(s[st][r], c, -m_use));
+                s[st][r] = p;
+                rs += p;
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m, mx);
-            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-            const float alpha = fast_exp2(m - m_use);
-            float rs = 0.f;
+        lsum = lsum * alpha + rs;
+        m = m_new;
 #pragma unroll
-            for (int st = 0; st < 2; ++st)
+        for (int i = 0; i < NDT; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float p = fast_exp2(s[st][r] - m_use);
-                    s[st][r] = p;
-                    rs += p;
-                }
-            lsum = lsum * alpha + rs;
-            m = m_new;
+            for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+        // O^T[d][q] += V^T[d][key] P^T[key][q]
 #pragma unroll
-            for (int i = 0; i < NDT; ++i)
+        for (int st = 0; st < 2; ++st)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
-            // O^T[d][q] += V^T[d][key] P^T[key][q]
+            for (int sk = 0; sk < 2; ++sk) {
+                const bf16x8 pf = pack8(s[st], sk);
 #pragma unroll
-            for (int st = 0; st < 2; ++st)
+                for (int d2 = 0; d2 < NDT; d2 += 2) {  // batches of 2 fragments keep the register budget at 256
+                    bf16x8 vf[2];
 #pragma unroll
-                for (int sk = 0; sk < 2; ++sk) {
-                    const bf16x8 pf = pack8(s[st], sk);
-                    bf16x8 vf[NDT];
-#pragma unroll
-                    for (int dt = 0; dt < NDT; ++dt)
-                        vf[dt] = tr_load(vt + (st * 32 + sk * 16) * (D * 2) + fo_v.tr1[dt],
-                                         vt + (st * 32 + sk * 16) * (D * 2) + fo_v.tr2[dt]);
+                    for (int dt = 0; dt < 2; ++dt)
+                        vf[dt] = tr_load(vt + (st * 32 + sk * 16) * (D * 2) + fo_v.tr1[d2 + dt],
+                                         vt + (st * 32 + sk * 16) * (D * 2) + fo_v.tr2[d2 + dt]);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int dt = 0; dt < NDT; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt], pf, o[dt], 0, 0, 0);
+                    for (int dt = 0; dt < 2; ++dt)
+                        o[d2 + dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt], pf, o[d2 + dt], 0, 0, 0);
                 }
+            }
+    };
+    stage(0, 0);
+    for (int kb = 0; kb < nblk; ++kb) {
+        const int cur = kb & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kb + 1 < nblk) stage(kb + 1, cur ^ 1);
+        const bool active = !CAUSAL || (kb * 64 <= q0 + 31);
+        if (active) {
+            // wave-uniform: does any element of this block need a mask?
+            const bool masked = (CAUSAL && (kb * 64 + 63 > q0)) || (kb * 64 + 64 > S) || (a.kmask != nullptr);
+            if (masked) block(std::true_type{}, kb, cur); else block(std::false_type{}, kb, cur);
         }
     }
     const float ltot = lsum + __shfl_xor(lsum, 32, 64);
