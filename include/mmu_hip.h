@@ -41,6 +41,12 @@ int mmu_gemm_uses_256(int M, int N, int K);
 int mmu_gemm_bf16_rope(int layout, const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                        const void* lora_u, const void* lora_b, int lora_k, const int* rope_pos, const void* rope_cos,
                        const void* rope_sin, int rope_cols, void* stream);
+/* Split-K GEMM for small outputs (skinny LoRA adapter wgrads: [32,in] and [out,32] reduced over all tokens): `splits`
+ * blocks per tile each reduce a K range and atomically add their fp32 partial into c32 [M][N] (zero on entry).
+ * mmu_fold_f32_into_bf16: dst_bf16 += c32 (* mask); c32 = 0. */
+int mmu_gemm_bf16_splitk(int layout, const void* A, const void* B, float* c32, int M, int N, int K, int lda, int ldb,
+                         int splits, void* stream);
+int mmu_fold_f32_into_bf16(float* src32, void* dst, const void* mask, long long n, void* stream);
 /* Tile configuration override (A/B tests, tuning): 0 = heuristic, 128 = 128x128x64 4-wave kernel,
  * 256 = 256x256x64 8-wave 8-phase kernel.  Process-wide. */
 int mmu_gemm_set_tile(int tile);

@@ -54,6 +54,10 @@ struct GemmArgs {
     const bf16* rope_cos;
     const bf16* rope_sin;
     int rope_cols;
+    // split-K (128^2 kernel, EPI 3): blockIdx.y takes K-tiles [y*kt_per_split, ...) and adds its fp32 partial tile into
+    // c32 [M][N] with atomics (tiny outputs only: skinny LoRA wgrads)
+    float* c32;
+    int kt_per_split;
 };
 
 __device__ __forceinline__ int swzT(int k) { return ((k & 3) << 1) | (((k >> 3) & 1) << 3); }
@@ -185,12 +189,15 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = (p.K + BK - 1) / BK;
-    stage_tile<AT>(smem, p.A, p.lda, m0, 0, p.M, p.K, wave, lane);
-    stage_tile<BT>(smem + TILE_BYTES, p.B, p.ldb, n0, 0, p.N, p.K, wave, lane);
+    const int nk_all = (p.K + BK - 1) / BK;
+    const int t_begin = (EPI == 3) ? blockIdx.y * p.kt_per_split : 0;
+    const int nk = (EPI == 3) ? min(nk_all, t_begin + p.kt_per_split) : nk_all;
+    if (t_begin >= nk) return;
+    stage_tile<AT>(smem, p.A, p.lda, m0, t_begin * BK, p.M, p.K, wave, lane);
+    stage_tile<BT>(smem + TILE_BYTES, p.B, p.ldb, n0, t_begin * BK, p.N, p.K, wave, lane);
 
-    for (int t = 0; t < nk; ++t) {
-        const int cur = t & 1;
+    for (int t = t_begin; t < nk; ++t) {
+        const int cur = (t - t_begin) & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();  // tile t landed for every wave; every wave is done reading buffer cur^1
         if (t + 1 < nk) {
@@ -237,8 +244,26 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             const int n = n0 + wn * 64 + nt * 16 + 4 * (lane >> 4);
-            epi_store<EPI>(p, m, n, acc[nt][mt]);
+            if (EPI == 3) {
+                if (m < p.M && n < p.N) {
+                    float* dst = p.c32 + (size_t)m * p.N + n;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) atomicAdd(dst + j, acc[nt][mt][j]);
+                }
+            } else {
+                epi_store<(EPI == 3 ? 0 : EPI)>(p, m, n, acc[nt][mt]);
+            }
         }
+    }
+}
+
+// dst_bf16[i] += src32[i]; src32[i] = 0   (fold a split-K fp32 accumulator into the bf16 gradient)
+__global__ void fold_f32_kernel(float* __restrict__ src, bf16* __restrict__ dst, const bf16* __restrict__ mask, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float v = src[i];
+        src[i] = 0.f;
+        if (mask) v *= bf2f(mask[i]);
+        dst[i] = f2bf(bf2f(dst[i]) + v);
     }
 }
 
@@ -679,4 +704,48 @@ extern "C" int mmu_gemm_bf16_rope(int layout, const void* A, const void* B, void
                                       lora_k, stream);
     g_rope = {nullptr, nullptr, nullptr, 0};
     return rc;
+}
+
+// Split-K GEMM for SMALL outputs (skinny LoRA wgrads): grid.y = splits blocks per tile each reduce a K range and
+// atomically add their fp32 partial into c32 [M][N] (must be zero on entry; left holding the result).
+// mmu_fold_f32_into_bf16 then adds it into the bf16 gradient (optionally through a 0/1 mask) and clears it.
+extern "C" int mmu_gemm_bf16_splitk(int layout, const void* A, const void* B, float* c32, int M, int N, int K, int lda,
+                                    int ldb, int splits, void* stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || splits < 1 || splits > 1024 || !c32) return -1;
+    if ((N & 7) || (lda & 7) || (ldb & 7)) return -1;
+    if (layout != 2 && (K & 7)) return -1;
+    if (layout == 2 && (M & 7)) return -1;
+    if (((uintptr_t)A | (uintptr_t)B) & 15) return -1;
+    GemmArgs a = {};
+    a.A = (const bf16*)A; a.B = (const bf16*)B; a.c32 = c32;
+    a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb;
+    a.tiles_m = (M + BM - 1) / BM; a.tiles_n = (N + BN - 1) / BN;
+    const int nk = (K + BK - 1) / BK;
+    a.kt_per_split = (nk + splits - 1) / splits;
+    const int ny = (nk + a.kt_per_split - 1) / a.kt_per_split;
+    hipStream_t s = (hipStream_t)stream;
+    auto go = [&](auto kern) -> int {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           4 * TILE_BYTES);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n, ny), dim3(256), 4 * TILE_BYTES, s, a);
+        hipError_t e2 = hipGetLastError();
+        return (int)e2;
+    };
+    switch (layout) {
+        case 0: return go(gemm_bf16_kernel<false, false, 3>);
+        case 1: return go(gemm_bf16_kernel<false, true, 3>);
+        case 2: return go(gemm_bf16_kernel<true, true, 3>);
+        default: return -1;
+    }
+}
+
+extern "C" int mmu_fold_f32_into_bf16(float* src32, void* dst, const void* mask, long long n, void* stream) {
+    if (n <= 0) return -1;
+    size_t grid = ((size_t)n + 255) / 256;
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(fold_f32_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, src32, (bf16*)dst,
+                       (const bf16*)mask, (size_t)n);
+    MMU_CHECK_LAUNCH();
+    return 0;
 }

@@ -24,6 +24,8 @@ SIGNATURES = {
     "mmu_gemm_bf16_lora": [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp],
     "mmu_gemm_uses_256": [_i, _i, _i],
     "mmu_gemm_bf16_rope": [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp],
+    "mmu_gemm_bf16_splitk": [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "mmu_fold_f32_into_bf16": [_vp, _vp, _vp, _ll, _vp],
     "mmu_gemm_set_tile": [_i],
     "mmu_gemm_set_group_m": [_i],
     "mmu_attn_fwd": [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp],
@@ -160,6 +162,17 @@ def gemm_rope(x, w, out, pos_ids, cos_t, sin_t, rope_cols, lora_u=None, lora_b=N
                                    _p(lora_b), kl, _p(pos_ids), _p(cos_t), _p(sin_t), rope_cols, _stream())
     _check(rc, "mmu_gemm_bf16_rope")
     return True
+
+
+def gemm_splitk_accumulate(layout, A, B, c32, dst, mask=None, splits=16):
+    """dst (bf16 [M,N]) += Aop @ Bop^T (* mask) through a split-K GEMM into the zeroed fp32 scratch c32 [M,N]."""
+    _bf16c(A, B, dst, mask)
+    assert c32.dtype == torch.float32 and c32.is_contiguous() and dst.is_contiguous()
+    M, N = dst.shape
+    K = A.shape[1] if layout != TN else A.shape[0]
+    rc = load().mmu_gemm_bf16_splitk(layout, _p(A), _p(B), _p(c32), M, N, K, A.stride(0), B.stride(0), splits, _stream())
+    _check(rc, "mmu_gemm_bf16_splitk")
+    _check(load().mmu_fold_f32_into_bf16(_p(c32), _p(dst), _p(mask), M * N, _stream()), "mmu_fold_f32_into_bf16")
 
 
 def gemm_set_group_m(g: int):

@@ -203,6 +203,7 @@ class LlavaHIP(nn.Module):
         self.transposed_wgrad = True
         self.transposed_wgrad_min_m = 1024
         self.fuse_rope = os.environ.get("MMU_NO_ROPE_FUSION", "0") != "1"  # A/B switch
+        self.lora_splitk_min_m = 2048
         if params is not None:
             self.load_params(params)
         elif init == "device":
@@ -341,6 +342,11 @@ class LlavaHIP(nn.Module):
         hip.gemm(hip.NT, x, self.w[wname], qkv, lora_u=U, lora_b=None if ad is None else ad.BL)
         hip.rope(qkv, pos, self._cos, self._sin, H, H, D, dt)
 
+    def _lora_scratch(self, n):
+        if getattr(self, "_lora_scr", None) is None or self._lora_scr.numel() < n:
+            self._lora_scr = torch.zeros(n, device=self.device, dtype=torch.float32)
+        return self._lora_scr
+
     def _lin_bwd(self, wname, dy, x, dx):
         """Backward of out = x W^T (+LoRA): accumulates the weight (or adapter) gradients, writes dx if given."""
         ad = self.lora.get(wname)
@@ -359,12 +365,20 @@ class LlavaHIP(nn.Module):
             else:
                 hip.gemm(hip.NN, dy, self.w[wname], dx, lora_u=Vs, lora_b=ad.A32T)
         base = wname[: -len(".weight")]
-        hip.gemm(hip.TN, Vs, x, self.g[base + ".lora_A"], accumulate=True)  # dA = s (dy B)^T x
+        gA, gB = self.g[base + ".lora_A"], self.g[base + ".lora_B"]
         U = torch.empty(M, ad.kl, device=dy.device, dtype=BF)
         hip.gemm(hip.NT, x, ad.A32s, U)
-        gB = self.g[base + ".lora_B"]
-        hip.gemm(hip.TN, dy, U, gB, accumulate=True)  # dB = s dy^T (x A^T); off-block entries are not parameters
-        gB.mul_(ad.mask)
+        if M >= self.lora_splitk_min_m:
+            # skinny outputs reduced over thousands of tokens: split-K over the tokens with fp32 accumulation
+            scr = self._lora_scratch(max(gA.numel(), gB.numel()))
+            hip.gemm_splitk_accumulate(hip.TN, Vs, x, scr[: gA.numel()].view(gA.shape), gA, None,
+                                       splits=max(1, min(64, M // 2048 * 2)))       # dA = s (dy B)^T x
+            hip.gemm_splitk_accumulate(hip.TN, dy, U, scr[: gB.numel()].view(gB.shape), gB, ad.mask,
+                                       splits=max(1, min(16, M // 4096)))           # dB = s dy^T (x A^T), block mask
+        else:
+            hip.gemm(hip.TN, Vs, x, gA, accumulate=True)
+            hip.gemm(hip.TN, dy, U, gB, accumulate=True)  # off-block entries are not parameters
+            gB.mul_(ad.mask)
 
     def init_random_(self, seed: int = 0, std: float = 0.02):
         """Random-init weights of the architecture, generated ON DEVICE (7B/13B: no host copy): N(0, std^2) for

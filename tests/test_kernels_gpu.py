@@ -579,3 +579,21 @@ def test_fused_rope_epilogue_and_bwd_store(dev):
     hip.attn_bwd(qkv[:, :dt], qkv[:, dt:2 * dt], qkv[:, 2 * dt:], o, lse, None, do, delta, d2[:, :dt], d2[:, dt:2 * dt],
                  d2[:, 2 * dt:], B, S, H, D, sc, True, rope=(pos, cos_t, sin_t))
     assert torch.equal(d2, d1)
+
+
+@pytest.mark.parametrize("layout", [hip.NT, hip.TN])
+def test_gemm_splitk_accumulate(dev, layout):
+    """Skinny output reduced over many tokens: split-K with fp32 atomics == the plain GEMM (integer data: exact)."""
+    M, N, K = 32, 264, 4000 if layout == hip.NT else 4104
+    a = _rand_int((M, K), dev, -2, 2, seed=1)
+    b = _rand_int((N, K), dev, -2, 2, seed=2)
+    A = a if layout == hip.NT else a.t().contiguous()
+    Bm = b if layout == hip.NT else b.t().contiguous()
+    dst0 = _rand_int((M, N), dev, -4, 4, seed=3)
+    mask = (torch.rand(M, N, device=dev) > 0.3).to(BF)
+    dst = dst0.clone()
+    scr = torch.zeros(M, N, device=dev, dtype=torch.float32)
+    hip.gemm_splitk_accumulate(layout, A, Bm, scr, dst, mask, splits=7)
+    ref = (dst0.float() + (a.float() @ b.float().t()) * mask.float()).to(BF)
+    assert torch.equal(dst, ref)
+    assert scr.abs().max().item() == 0

@@ -417,3 +417,23 @@ def test_eval_truth_ratio_pass_vs_reference_golden(models):
                                                  ("avg_paraphrased_loss", "average_perturb_loss")}}
     fq = metrics.evaluate_forget_quality(as_log(logs), {"eval_log_forget.json": gold["logs"]})
     assert fq["KS test p-value"] > 0.99 and fq["JS metric"] < 1e-3, fq
+
+
+def test_lora_splitk_wgrad_path_matches(dev):
+    """Adapter wgrads through the split-K fp32 path (used for >= 2048 tokens) == the plain TN GEMM path."""
+    from multimodal_unlearning_amd.llava import LlavaHIP, LoraSpec
+    from multimodal_unlearning_amd.trainer import MMTrainerForgetting
+
+    cfg = tiny_test_config()
+    model = LlavaHIP(cfg, init_params(cfg, seed=0), device=dev, lora=LoraSpec(r=8, alpha=32.0))
+    model.init_lora_(seed=3, b_std=0.02)
+    inputs = make_forget_batch(cfg, 4, 64, seed=23, n_question=9)
+    tr = MMTrainerForgetting(model=model, forget_loss="grad_ascent", teacher_model=None, loss_beta=1.0, l1_lambda=0,
+                             l0_lambda=0, l_norm_from="zero")
+    res = []
+    for thr in (1 << 30, 0):
+        model.lora_splitk_min_m = thr
+        model.ensure_grad().zero_()
+        tr.compute_loss(model, inputs).backward()
+        res.append(model.ensure_grad().clone())
+    assert _relerr(res[1], res[0]) < 3e-3, _relerr(res[1], res[0])
