@@ -161,6 +161,60 @@ def cpu_baseline(cfg, S, budget_layers=1, clip_layers=2):
                        f"linearly to full depth ({est:.0f}s per sample)")}
 
 
+def hbm_kernels(hip, cfg, n_seq, S, dev, reps=5):
+    """each HBM-bound kernel of the step, standalone at the workload's shapes: algorithmic bytes next to
+    the measured GB/s (torch events on the stream the C-ABI launches on), vs the 8 TB/s HBM3E peak."""
+    BF = torch.bfloat16
+    t = cfg.text
+    M, d, I, V = n_seq * S, t.hidden_size, t.intermediate_size, t.vocab_size
+    g = torch.Generator(device=dev).manual_seed(7)
+    rnd = lambda *sh: torch.randn(*sh, device=dev, dtype=BF, generator=g)
+    x, dy, dres, y = rnd(M, d), rnd(M, d), rnd(M, d), torch.empty(M, d, device=dev, dtype=BF)
+    w = torch.ones(d, device=dev, dtype=BF)
+    rstd = torch.empty(M, device=dev, dtype=torch.float32)
+    dwp = torch.empty(hip.rmsnorm_bwd_nparts(M) * d, device=dev, dtype=torch.float32)
+    dw = torch.zeros(d, device=dev, dtype=BF)
+    gu, act, dgu = rnd(M, 2 * I), torch.empty(M, I, device=dev, dtype=BF), torch.empty(M, 2 * I, device=dev, dtype=BF)
+    dguT = torch.empty(2 * I, M, device=dev, dtype=BF)
+    logits = rnd(M, V)
+    dlog = rnd(M, V)
+    labels = torch.randint(0, V, (n_seq, S), device=dev, generator=g)
+    lse = torch.empty(M, device=dev, dtype=torch.float32)
+    lrow = torch.empty(M, device=dev, dtype=torch.float32)
+    seg_scale = torch.ones(1, device=dev, dtype=torch.float32)
+    seg_cnt = torch.full((1,), float(n_seq * (S - 1)), device=dev, dtype=torch.float32)
+    stats = torch.empty(M, 4, device=dev, dtype=torch.float32)
+    coef = torch.ones(1, device=dev, dtype=torch.float32)
+    NP = 1 << 28
+    p, gr = rnd(NP), rnd(NP)
+    m1, v1 = torch.zeros(NP, device=dev), torch.zeros(NP, device=dev)
+    ss = torch.ones(1, device=dev, dtype=torch.float32)
+    cases = [
+        ("rmsnorm_fwd", 2 * M * d * 2 + M * 4, lambda: hip.rmsnorm_fwd(x, w, y, rstd, 1e-5)),
+        ("rmsnorm_bwd (+residual grad, dgamma partials)", 4 * M * d * 2, lambda: hip.rmsnorm_bwd(dy, x, w, rstd, dres, y, dwp, dw, True)),
+        ("swiglu_fwd", 3 * M * I * 2, lambda: hip.swiglu_fwd(gu, act)),
+        ("swiglu_bwd_t (dgu and dgu^T)", 7 * M * I * 2, lambda: hip.swiglu_bwd_t(gu, act, dgu, dguT)),
+        ("ce_fwd (logits once)", M * V * 2, lambda: hip.ce_fwd(logits, labels, lse, lrow, S)),
+        ("ce_bwd (logits -> dlogits)", 2 * M * V * 2, lambda: hip.ce_bwd(logits, labels, lse, seg_scale, seg_cnt, M, True, dlog, S)),
+        ("rowloss_fwd KL (student+teacher logits)", 2 * M * V * 2, lambda: hip.rowloss_fwd(hip.KL_STUDENT_INPUT, logits, dlog, 1.0, stats)),
+        ("adamw (bf16 p,g; fp32 m,v; grad zeroed)", 24 * NP, lambda: hip.adamw(p, gr, m1, v1, 1e-5, 0.9, 0.999, 1e-8, 0.01, 1, ss, 1.0)),
+        ("sumsq (grad norm)", 2 * NP, lambda: hip.sumsq(gr, ss)),
+    ]
+    out = []
+    for name, nbytes, fn in cases:
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        e1.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / reps
+        out.append({"kernel": name, "algorithmic_bytes": nbytes, "us": round(us, 1),
+                    "GBps": round(nbytes / us / 1e3, 1), "frac_of_8TBps": round(nbytes / us / 1e3 / 8000, 3)})
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -175,6 +229,8 @@ def main():
     ap.add_argument("--loss", default="grad_diff_forget_ce_retain_ce")
     ap.add_argument("--layers", type=int, default=0, help="debug: override decoder depth (invalidates the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--hbm-kernels", action="store_true",
+                    help="also time the step's HBM-bound kernels standalone (bytes next to GB/s) after the timed region")
     ap.add_argument("--no-fuse", action="store_true")
     ap.add_argument("--no-wt", action="store_true", help="do not keep resident W^T copies (saves one weight copy of HBM)")
     ap.add_argument("--lora-r", type=int, default=0, help="LoRA rank (0 = full fine-tuning); BASELINE config 2 uses 8")
@@ -288,6 +344,9 @@ def main():
                          "launches": n, "avg_launch_us": round(t / n * 1e6, 1),
                          "gemm_share_of_step": round(t / (elapsed / args.steps), 3), "by_layout": by},
         }
+        if args.hbm_kernels and world == 1:
+            torch.cuda.empty_cache()
+            out["hbm_kernels"] = hbm_kernels(hip, cfg, 2 * B if paired else B, S, dev)
         if not args.no_cpu_baseline and args.model != "tiny" and world == 1:  # rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(cfg, S)
         elif args.model == "tiny":
