@@ -80,6 +80,11 @@ int mmu_layernorm_fwd(const void* x, const void* w, const void* b, void* y, int 
 
 /* ---- CLIP embeddings (CLIPVisionEmbeddings: patch conv as im2col+GEMM, cls/pos add; K1,K2) ---- */
 int mmu_im2col_patch(const float* pix, void* out, int B, int C, int H, int P, int Kpad, void* stream);
+/* CLIP image rescale + normalise on the device (replaces the processor's numpy rescale/normalize reached from
+ * mm/dataset.py:310-317 `processor(text=..., images=...)`): in_u8 [n_img][3][hw] uint8 (resized + centre-cropped on
+ * the host) -> out fp32 (x/255 - mean[c]) / std[c].  mean3/std3: HOST pointers to 3 floats.  hw % 16 == 0. */
+int mmu_clip_normalize_u8(const void* in_u8, float* out, long long n_img, int hw, const float* mean3, const float* std3,
+                          void* stream);
 int mmu_clip_embed(const void* patch, const void* cls, const void* pos, void* out, int B, int T, int d, void* stream);
 
 /* ---- RoPE on the fused qkv buffer, rotate-half convention (apply_rotary_pos_emb; K9) ---- */

@@ -58,3 +58,77 @@ def load_pretrained(cfg: LlavaConfig, path: str):
     for f in files:
         sd.update(load_file(os.path.join(path, f)))
     return from_hf_state_dict(cfg, sd, detect_hf_style(sd.keys()))
+
+
+# ------------------------------------------------------------------------------------------------ LoRA adapters
+_FUSED = {"qkv": ("self_attn.", ("q_proj", "k_proj", "v_proj")), "o": ("self_attn.", ("o_proj",)),
+          "gate_up": ("mlp.", ("gate_proj", "up_proj")), "down": ("mlp.", ("down_proj",))}
+
+
+def _peft_modules(cfg: LlavaConfig, base: str, style: str):
+    """Our (possibly fused) module name -> the HF module paths peft would have wrapped, in fused order."""
+    from .params import _hf_prefixes
+
+    _, pj, lm, head = _hf_prefixes(style)
+    if base.startswith("projector."):
+        return [pj + base[len("projector."):]]
+    if base == "lm_head":
+        return [head[:-1]]
+    _, _, i, key = base.split(".")  # text.layers.<i>.<key>
+    sub, names = _FUSED[key]
+    return [f"{lm}layers.{i}.{sub}{n}" for n in names]
+
+
+def lora_state_to_peft(cfg: LlavaConfig, state, style: str = "hf4"):
+    """Compact fused adapter tensors (LlavaHIP.lora_state) -> peft's `adapter_model.safetensors` names:
+    base_model.model.<module>.lora_A.weight [r,in] / lora_B.weight [out,r], one pair per un-fused HF Linear."""
+    out = OrderedDict()
+    for k in state:
+        if not k.endswith(".lora_A"):
+            continue
+        base = k[: -len(".lora_A")]
+        A, Bm = state[k], state[base + ".lora_B"]
+        mods = _peft_modules(cfg, base, style)
+        r, seg = A.shape[0] // len(mods), Bm.shape[0] // len(mods)
+        for j, m in enumerate(mods):
+            out[f"base_model.model.{m}.lora_A.weight"] = A[j * r:(j + 1) * r].contiguous()
+            out[f"base_model.model.{m}.lora_B.weight"] = Bm[j * seg:(j + 1) * seg].contiguous()
+    return out
+
+
+def lora_state_from_peft(cfg: LlavaConfig, sd, bases, style: str | None = None):
+    """peft names -> compact fused tensors for the module list `bases` (e.g. [n[:-7] for n in model.lora])."""
+    if style is None:
+        style = "hf4" if any(".language_model.model." in k for k in sd) else "hf5"
+    out = OrderedDict()
+    for base in bases:
+        mods = _peft_modules(cfg, base, style)
+        try:
+            out[base + ".lora_A"] = torch.cat([sd[f"base_model.model.{m}.lora_A.weight"] for m in mods])
+            out[base + ".lora_B"] = torch.cat([sd[f"base_model.model.{m}.lora_B.weight"] for m in mods])
+        except KeyError as e:
+            raise KeyError(f"adapter file has no tensors for {base} ({e})") from None
+    return out
+
+
+def save_adapter(cfg: LlavaConfig, state, out_dir: str, r: int, alpha: float, style: str = "hf4"):
+    """peft-layout adapter directory: adapter_model.safetensors + the fields of adapter_config.json we use."""
+    os.makedirs(out_dir, exist_ok=True)
+    save_file({k: v.contiguous() for k, v in lora_state_to_peft(cfg, state, style).items()},
+              os.path.join(out_dir, "adapter_model.safetensors"))
+    json.dump({"peft_type": "LORA", "r": r, "lora_alpha": alpha, "lora_dropout": 0.0, "bias": "none",
+               "task_type": "CAUSAL_LM"}, open(os.path.join(out_dir, "adapter_config.json"), "w"), indent=2)
+
+
+def load_adapter(cfg: LlavaConfig, path: str, bases):
+    """-> (compact fused state, r, alpha) from a peft-layout adapter directory (safetensors only)."""
+    conf = json.load(open(os.path.join(path, "adapter_config.json")))
+    sd = load_file(os.path.join(path, "adapter_model.safetensors"))
+    return lora_state_from_peft(cfg, sd, bases), int(conf["r"]), float(conf["lora_alpha"])
+
+
+def merge_adapter_and_save(model, out_dir: str, style: str = "hf4"):
+    """mm/forget.py:100-113: fold the loaded adapter into the base weights and save a plain HF-layout checkpoint
+    "so that we can again do PEFT style finetuning from scratch"."""
+    model.merge_lora_()
+    return save_pretrained(model.cfg, model.w, out_dir, style=style)

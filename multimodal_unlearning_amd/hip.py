@@ -38,6 +38,7 @@ SIGNATURES = {
     "mmu_rmsnorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "mmu_layernorm_fwd": [_vp, _vp, _vp, _vp, _i, _i, _f, _vp],
     "mmu_im2col_patch": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "mmu_clip_normalize_u8": [_vp, _vp, _ll, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _vp],
     "mmu_clip_embed": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "mmu_rope_table": [_vp, _vp, _i, _i, _f, _vp],
     "mmu_rope": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
@@ -238,6 +239,16 @@ def im2col_patch(pix, out, P):
     B, Cc, Hh, Ww = pix.shape
     assert Hh == Ww
     _check(load().mmu_im2col_patch(_p(pix), _p(out), B, Cc, Hh, P, out.shape[1], _stream()), "mmu_im2col_patch")
+    return out
+
+
+def clip_normalize_u8(u8, out, mean, std):
+    """uint8 [n,3,H,W] -> fp32 (x/255 - mean[c]) / std[c] (CLIP processor rescale + normalize) on the device."""
+    assert u8.dtype == torch.uint8 and out.dtype == torch.float32 and u8.is_cuda and out.is_cuda
+    assert u8.is_contiguous() and out.is_contiguous() and u8.shape == out.shape and u8.shape[1] == 3
+    n, _, Hh, Ww = u8.shape
+    m3, s3 = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
+    _check(load().mmu_clip_normalize_u8(_p(u8), _p(out), n, Hh * Ww, m3, s3, _stream()), "mmu_clip_normalize_u8")
     return out
 
 

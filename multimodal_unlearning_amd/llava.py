@@ -319,6 +319,38 @@ class LlavaHIP(nn.Module):
                                                for j in range(ad.k)]).detach().float().cpu()
         return out
 
+    def load_lora_state_(self, state):
+        """Inverse of lora_state(): compact peft-shaped tensors -> the padded, block-masked adapter buffers."""
+        with torch.no_grad():
+            for wname, ad in self.lora.items():
+                base = wname[: -len(".weight")]
+                A, Bm = state[base + ".lora_A"], state[base + ".lora_B"]
+                if tuple(A.shape) != (ad.k * ad.r, ad.A32.shape[1]) or tuple(Bm.shape) != (ad.BL.shape[0], ad.r):
+                    raise ValueError(f"adapter shape mismatch for {base}: {tuple(A.shape)} / {tuple(Bm.shape)}")
+                ad.A32.zero_()
+                ad.A32[: ad.k * ad.r].copy_(A.to(self.device, BF))
+                ad.BL.zero_()
+                seg = ad.BL.shape[0] // ad.k
+                for j in range(ad.k):
+                    ad.BL[j * seg:(j + 1) * seg, j * ad.r:(j + 1) * ad.r].copy_(Bm[j * seg:(j + 1) * seg].to(self.device, BF))
+        self.refresh_derived()
+
+    def merge_lora_(self):
+        """peft `merge_and_unload` (mm/forget.py:111-113) on the device: W += (alpha/r) B A for every adapted Linear as
+        one accumulate-epilogue GEMM each (fp32 accumulation, ONE bf16 rounding of W + delta; peft rounds the delta to
+        bf16 first — peft is absent here, so this step is "parity unpinned" against peft itself and pinned against the
+        formula).  The adapters are then reset to the identity (B = 0) so the model keeps computing the same function."""
+        if not self.lora:
+            raise ValueError("merge_lora_ needs a model built with lora=LoraSpec(...)")
+        self.refresh_derived()
+        with torch.no_grad():
+            for wname, ad in self.lora.items():
+                hip.gemm(hip.NN, ad.BLs, ad.A32, self.w[wname], accumulate=True)  # [out,kl] x [kl,in]; off-block BLs = 0
+                ad.BL.zero_()
+        self.refresh_derived()
+        if self.wT:
+            self.refresh_transposed_weights()
+
     def _lin_fwd(self, wname, x, out, bias=None, resid=None):
         """out = x W^T (+ bias) (+ resid), plus the fused LoRA term when `wname` carries an adapter."""
         ad = self.lora.get(wname)

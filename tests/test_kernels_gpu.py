@@ -5,6 +5,8 @@ operand maps); otherwise the tolerance is written next to the assert.
 """
 import math
 
+import numpy as np
+
 import pytest
 import torch
 
@@ -597,3 +599,31 @@ def test_gemm_splitk_accumulate(dev, layout):
     ref = (dst0.float() + (a.float() @ b.float().t()) * mask.float()).to(BF)
     assert torch.equal(dst, ref)
     assert scr.abs().max().item() == 0
+
+
+def test_clip_normalize_u8_matches_processor(dev):
+    """HIP rescale+normalise of uint8 pixels == the reference processor's fp32 pixel_values (golden digest from
+    oracle/make_golden_collator.py) bit for bit, and == the numpy restatement on every byte value."""
+    import json
+    import os
+
+    from multimodal_unlearning_amd import collator as C
+    from oracle.tiny_tokenizer import adapter, pixel_digest, test_image as make_image
+
+    G = os.path.join(os.path.dirname(__file__), "golden")
+    npz, meta = np.load(os.path.join(G, "collator.npz")), json.load(open(os.path.join(G, "collator_pairs.json")))
+    c = meta["cases"]["basic_left"]
+    samples = [dict(s, image=make_image(*meta["images"][s["image"]]) if s["image"] is not None else None) for s in c["samples"]]
+    out = C.mm_data_collator_preprocessor(samples, adapter("left"), c["max_length"], device=dev)
+    assert "pixel_values_u8" not in out and out["pixel_values"].dtype == torch.float32 and out["input_ids"].is_cuda
+    d = pixel_digest(out["pixel_values"].cpu().numpy())
+    assert np.array_equal(d["sub"], npz["basic_left.pixel_values.sub"])
+    for k in ("sum", "sumsq", "wsum"):
+        assert d[k] == float(npz[f"basic_left.pixel_values.{k}"]), k
+    # every byte value in every channel
+    u8 = (torch.arange(2 * 3 * 16 * 32, dtype=torch.int64) % 256).to(torch.uint8).reshape(2, 3, 16, 32)
+    pv = torch.empty(u8.shape, device=dev, dtype=torch.float32)
+    hip.clip_normalize_u8(u8.to(dev), pv, C.OPENAI_CLIP_MEAN, C.OPENAI_CLIP_STD)
+    r = (u8.numpy().astype(np.float64) * (1 / 255)).astype(np.float32)
+    ref = (r - np.array(C.OPENAI_CLIP_MEAN, np.float32).reshape(1, 3, 1, 1)) / np.array(C.OPENAI_CLIP_STD, np.float32).reshape(1, 3, 1, 1)
+    assert np.array_equal(pv.cpu().numpy(), ref)

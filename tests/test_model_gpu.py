@@ -437,3 +437,48 @@ def test_lora_splitk_wgrad_path_matches(dev):
         tr.compute_loss(model, inputs).backward()
         res.append(model.ensure_grad().clone())
     assert _relerr(res[1], res[0]) < 3e-3, _relerr(res[1], res[0])
+
+
+def test_lora_merge_and_adapter_io(dev, tmp_path):
+    """mm/forget.py:100-113 flow: load a peft-layout adapter, merge it into the base weights on the device, save a plain
+    checkpoint.  Merged logits == adapter logits (bf16 tolerance), merged weights == W + (alpha/r) B A (fp32 formula,
+    one bf16 rounding), and a fresh non-LoRA model loaded from the saved checkpoint computes the merged function."""
+    from multimodal_unlearning_amd.checkpoint import load_adapter, load_pretrained, merge_adapter_and_save, save_adapter
+    from multimodal_unlearning_amd.llava import LlavaHIP, LoraSpec
+    from multimodal_unlearning_amd.synthetic import make_split
+
+    cfg = tiny_test_config()
+    P = init_params(cfg, seed=0)
+    spec = LoraSpec(r=8, alpha=32.0)
+    src = LlavaHIP(cfg, P, device=dev, lora=spec)
+    src.init_lora_(seed=5, b_std=0.05)
+    save_adapter(cfg, src.lora_state(), str(tmp_path / "adapter"), r=8, alpha=32.0)
+
+    model = LlavaHIP(cfg, P, device=dev, lora=spec)
+    st, r, alpha = load_adapter(cfg, str(tmp_path / "adapter"), [n[: -len(".weight")] for n in model.lora])
+    assert (r, alpha) == (8, 32.0)
+    model.load_lora_state_(st)
+    for wname, ad in model.lora.items():
+        assert torch.equal(ad.A32, src.lora[wname].A32) and torch.equal(ad.BL, src.lora[wname].BL), wname
+    sp = make_split(cfg, 2, 40, seed=31, n_question=7)
+    sp = {k: v.to(dev) for k, v in sp.items()}
+    with torch.no_grad():
+        before = model.logits(sp["input_ids"], sp["attention_mask"], sp["pixel_values"]).float()
+    expect = {}
+    for wname, ad in model.lora.items():
+        expect[wname] = (model.w[wname].float() + spec.scaling * (ad.BL.float() @ ad.A32.float())).to(torch.bfloat16)
+    files = merge_adapter_and_save(model, str(tmp_path / "merged"))
+    assert files
+    for wname, ad in model.lora.items():
+        diff = (model.w[wname].float() - expect[wname].float()).abs()
+        # fp32 accumulate + one rounding on both sides; only fp32 summation order may flip a rounding tie (1 bf16 ulp)
+        assert float(diff.max()) <= 2.0 ** -7 * float(expect[wname].float().abs().max()), wname
+        assert float((diff > 0).float().mean()) < 1e-2, wname
+        assert float(ad.BL.abs().max()) == 0.0
+    with torch.no_grad():
+        after = model.logits(sp["input_ids"], sp["attention_mask"], sp["pixel_values"]).float()
+    assert _relerr(after, before) < 2e-2, _relerr(after, before)  # bf16: delta folded into W vs added in the epilogue
+    plain = LlavaHIP(cfg, load_pretrained(cfg, str(tmp_path / "merged")), device=dev)
+    with torch.no_grad():
+        again = plain.logits(sp["input_ids"], sp["attention_mask"], sp["pixel_values"]).float()
+    assert torch.equal(again, after)
