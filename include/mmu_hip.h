@@ -52,6 +52,9 @@ int mmu_fold_f32_into_bf16(float* src32, void* dst, const void* mask, long long 
 int mmu_gemm_set_tile(int tile);
 /* Tile rasterisation of the 256x256 kernel (tuning): GROUP_M tile rows swept column by column; 0 = default. */
 int mmu_gemm_set_group_m(int group_m);
+/* 256x256 kernel launch mode (A/B tests): 0 = one workgroup per tile (default); 1 = persistent, 256 workgroups walk
+ * the tiles. */
+int mmu_gemm_set_persistent(int mode);
 
 /* ---- Attention (replaces the flash-attn wheel: mm/forget.py:86,98,106 attn_implementation=
  * "flash_attention_2"; SURVEY §8a K3 (CLIP, non-causal, head_dim 64) and K10 (Llama, causal, 128)) ----

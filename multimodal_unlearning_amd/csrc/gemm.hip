@@ -27,6 +27,8 @@ struct RopeReq { const int* pos; const bf16* cos; const bf16* sin; int cols; };
 static RopeReq g_rope = {nullptr, nullptr, nullptr, 0};  // set only for the duration of mmu_gemm_bf16_rope
 static int g_force_tile = 0;  // mmu_gemm_set_tile
 static int g_group_m = 0;     // mmu_gemm_set_group_m
+static int g_persist = 0;     // mmu_gemm_set_persistent: 0 one workgroup per tile; 1 persistent (256 workgroups walk the tiles)
+static int g_num_cu = 256;    // MI355X
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -157,6 +159,43 @@ __device__ __forceinline__ void epi_store(const GemmArgs& p, int m, int n, const
 #pragma unroll
     for (int j = 0; j < 4; ++j) out[j] = f2bf(o[j]);
     *reinterpret_cast<bf16x4*>(cp) = out;
+}
+
+// 8 consecutive columns of one row (16-B store; bias / residual / C read as 16-B loads): the 256^2 kernel's epilogue
+// after the cross-lane swap.  Rounding points as in epi_store.
+template <int EPI>
+__device__ __forceinline__ void epi_store8(const GemmArgs& p, int m, int n, const f32x4 lo, const f32x4 hi) {
+    if (m >= p.M || n >= p.N) return;  // N % 8 == 0: the chunk is all in or all out
+    bf16* cp = p.C + (size_t)m * p.ldc + n;
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { o[j] = lo[j]; o[4 + j] = hi[j]; }
+    if (EPI == 1) {
+        if (p.bias) {
+            const bf16x8 b = *reinterpret_cast<const bf16x8*>(p.bias + n);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] += bf2f(b[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = round_bf16(o[j]);
+        if (p.act) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = round_bf16(act_apply(o[j], p.act));
+        }
+        if (p.resid) {
+            const bf16x8 r = *reinterpret_cast<const bf16x8*>(p.resid + (size_t)m * p.ldr + n);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] += bf2f(r[j]);
+        }
+    } else if (EPI == 2) {
+        const bf16x8 c = *reinterpret_cast<const bf16x8*>(cp);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] += bf2f(c[j]);
+    }
+    bf16x8 out;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) out[j] = f2bf(o[j]);
+    *reinterpret_cast<bf16x8*>(cp) = out;
 }
 
 template <bool AT, bool BT, int EPI>
@@ -370,38 +409,36 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave >> 2, wn = wave & 3;
 
-    int pid = blockIdx.x;
-    {
-        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = pid & 7, loc = pid >> 3;
-        pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-    }
-    const int GROUP_M = p.group_m;
-    const int per_group = GROUP_M * p.tiles_n;
-    const int gid = pid / per_group;
-    const int first_m = gid * GROUP_M;
-    const int gsz = min(p.tiles_m - first_m, GROUP_M);
-    const int tile_m = first_m + (pid % per_group) % gsz;
-    const int tile_n = (pid % per_group) / gsz;
-    const int m0 = tile_m * 256, n0 = tile_n * 256;
+    // Virtual tile id -> (m0, n0): bijective XCD-aware remap (virtual ids congruent mod 8 stay on one XCD, also in
+    // the persistent launch where block b walks ids b, b + grid, ...), then GROUP_M rasterisation.
+    const int total_tiles = p.tiles_m * p.tiles_n;
+    auto decode = [&](int vt, int& m0_, int& n0_) {
+        int pid = vt;
+        {
+            const int nwg = total_tiles, q = nwg >> 3, r = nwg & 7, xcd = pid & 7, loc = pid >> 3;
+            pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+        }
+        const int GROUP_M = p.group_m;
+        const int per_group = GROUP_M * p.tiles_n;
+        const int gid = pid / per_group;
+        const int first_m = gid * GROUP_M;
+        const int gsz = min(p.tiles_m - first_m, GROUP_M);
+        m0_ = (first_m + (pid % per_group) % gsz) * 256;
+        n0_ = ((pid % per_group) / gsz) * 256;
+    };
 
     // LDS map: buffer d in {0,1}: [A-h0 | A-h1 | B-h0 | B-h1], 16 KiB each
     auto buf = [&](int d, int op, int h) -> char* { return smem + ((d * 2 + op) * 2 + h) * HB; };
 
-    const StageDesc dA0 = make_desc<AT, true>(p.A, p.lda, m0, 0, p.M, wave, lane);
-    const StageDesc dA1 = make_desc<AT, true>(p.A, p.lda, m0, 1, p.M, wave, lane);
-    const StageDesc dB0 = make_desc<BT, false>(p.B, p.ldb, n0, 0, p.N, wave, lane);
-    const StageDesc dB1 = make_desc<BT, false>(p.B, p.ldb, n0, 1, p.N, wave, lane);
+    int vt = blockIdx.x;
+    int m0, n0;
+    decode(vt, m0, n0);
+    StageDesc dA0 = make_desc<AT, true>(p.A, p.lda, m0, 0, p.M, wave, lane);
+    StageDesc dA1 = make_desc<AT, true>(p.A, p.lda, m0, 1, p.M, wave, lane);
+    StageDesc dB0 = make_desc<BT, false>(p.B, p.ldb, n0, 0, p.N, wave, lane);
+    StageDesc dB1 = make_desc<BT, false>(p.B, p.ldb, n0, 1, p.N, wave, lane);
 
     f32x4 acc[2][2][2][4];  // [a][b][nt][mt]
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) acc[a][b][nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
     bf16x8 fa[2][4];     // [ks][mt]   current A block
     bf16x8 fb[2][2][2];  // [b][ks][nt]
 
@@ -437,13 +474,29 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     } while (0)
 
     // prologue: K-tile 0 complete in d0; B-h0, A-h0, B-h1 of K-tile 1 in flight towards d1
-    G256_STAGE_A(dA0, 0, 0, 0);
-    G256_STAGE_B(dB0, 0, 0, 0);
-    G256_STAGE_B(dB1, 0, 1, 0);
-    G256_STAGE_A(dA1, 0, 1, 0);
-    G256_STAGE_B(dB0, 1, 0, 1);
-    G256_STAGE_A(dA0, 1, 0, 1);
-    G256_STAGE_B(dB1, 1, 1, 1);
+#define G256_PROLOGUE()              \
+    do {                             \
+        G256_STAGE_A(dA0, 0, 0, 0);  \
+        G256_STAGE_B(dB0, 0, 0, 0);  \
+        G256_STAGE_B(dB1, 0, 1, 0);  \
+        G256_STAGE_A(dA1, 0, 1, 0);  \
+        G256_STAGE_B(dB0, 1, 0, 1);  \
+        G256_STAGE_A(dA0, 1, 0, 1);  \
+        G256_STAGE_B(dB1, 1, 1, 1);  \
+    } while (0)
+    G256_PROLOGUE();
+
+  for (;;) {  // persistent launch: this block's tiles vt, vt + grid, ... (one pass when grid == tiles)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) acc[a][b][nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // vmcnt counts in issue order: with the epilogue stores of the previous tile issued after this prologue, this
+    // also waits for all but the last 6 of them
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     G256_BAR();
     // Stagger: the wm=1 waves (the second wave of every SIMD) run one barrier behind the wm=0 waves, so on each
@@ -537,33 +590,68 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
         }
     }
 
+    // Next tile (persistent launch): decode it now, stage its prologue after the epilogue.  (Measured on MI355X:
+    // requesting the prologue BEFORE the epilogue stores gains nothing, because vmcnt retires in issue order and the
+    // first counted wait of the next tile then also waits for the stores; a start skew between CUs costs more than
+    // the store bursts it spreads; the persistent launch itself is worth < 0.2 % and is off by default.)
+    const int cm0 = m0, cn0 = n0;
+    vt += gridDim.x;
+    const bool more = vt < total_tiles;
+    if (more) {
+        decode(vt, m0, n0);
+        dA0 = make_desc<AT, true>(p.A, p.lda, m0, 0, p.M, wave, lane);
+        dA1 = make_desc<AT, true>(p.A, p.lda, m0, 1, p.M, wave, lane);
+        dB0 = make_desc<BT, false>(p.B, p.ldb, n0, 0, p.N, wave, lane);
+        dB1 = make_desc<BT, false>(p.B, p.ldb, n0, 1, p.N, wave, lane);
+    }
+
+    // Epilogue.  The MFMA leaves each lane with 4 consecutive columns of one row per (nt) tile: stored as is, a wave
+    // store covers 16 rows x 32 B and every 128-B line of C is written by four separate partial-line requests (the
+    // stores were 8-9 % of a K=4096 GEMM).  v_permlane16_swap exchanges the odd 16-lane rows of the nt=0 tile with the
+    // even rows of the nt=1 tile, after which a lane owns 8 consecutive columns (one 16-B store, 64-B runs per row):
+    //   lane group g = lane>>4:  columns (g&1)*16 + (g>>1)*8 .. +7 of the wave's 32-column run.
+    // b = 0 / 1 are swapped identically, so they stay the two halves (c, c + 64) of a RoPE pair.
+    {
+    const int g4 = lane >> 4;
+    const int cih = (wn & 1) * 32 + (g4 & 1) * 16 + (g4 >> 1) * 8;  // column inside the 128-wide group (< 64)
+    const int n = cn0 + (wn >> 1) * 128 + cih;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
-            const int m = m0 + wm * 128 + a * 64 + mt * 16 + (lane & 15);
-            const int pos = (EPI == 0 && p.rope_pos && m < p.M) ? p.rope_pos[m] : 0;
+            const int m = cm0 + wm * 128 + a * 64 + mt * 16 + (lane & 15);
+            f32x4 y[2][2];  // [b][first / second 4 columns]
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                // b = 0 / 1 are columns c and c + 64 of the same 128-wide group: the two halves of a RoPE pair
-                const int cih = (wn & 1) * 32 + nt * 16 + 4 * (lane >> 4);  // column inside the 128-wide group (< 64)
-                const int n = n0 + (wn >> 1) * 128 + cih;
-                f32x4 v0 = acc[a][0][nt][mt], v1 = acc[a][1][nt][mt];
-                if (EPI == 0 && p.rope_pos && n < p.rope_cols && m < p.M) {
-                    const bf16x4 c4 = *reinterpret_cast<const bf16x4*>(p.rope_cos + (size_t)pos * 64 + cih);
-                    const bf16x4 s4 = *reinterpret_cast<const bf16x4*>(p.rope_sin + (size_t)pos * 64 + cih);
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[a][b][0][mt][j]),
+                                                                    __float_as_uint(acc[a][b][1][mt][j]), false, false);
+                    y[b][0][j] = __uint_as_float(r[0]);
+                    y[b][1][j] = __uint_as_float(r[1]);
+                }
+            if (EPI == 0 && p.rope_pos && n < p.rope_cols && m < p.M) {
+                const int pos = p.rope_pos[m];
+                const bf16x8 c8 = *reinterpret_cast<const bf16x8*>(p.rope_cos + (size_t)pos * 64 + cih);
+                const bf16x8 s8 = *reinterpret_cast<const bf16x8*>(p.rope_sin + (size_t)pos * 64 + cih);
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const float x1 = round_bf16(v0[j]), x2 = round_bf16(v1[j]);
-                        const float cf = bf2f(c4[j]), sf = bf2f(s4[j]);
-                        v0[j] = round_bf16(x1 * cf) + round_bf16(-x2 * sf);
-                        v1[j] = round_bf16(x2 * cf) + round_bf16(x1 * sf);
+                        const float x1 = round_bf16(y[0][h][j]), x2 = round_bf16(y[1][h][j]);
+                        const float cf = bf2f(c8[h * 4 + j]), sf = bf2f(s8[h * 4 + j]);
+                        y[0][h][j] = round_bf16(x1 * cf) + round_bf16(-x2 * sf);
+                        y[1][h][j] = round_bf16(x2 * cf) + round_bf16(x1 * sf);
                     }
-                }
-                epi_store<EPI>(p, m, n, v0);
-                epi_store<EPI>(p, m, n + 64, v1);
             }
+            epi_store8<EPI>(p, m, n, y[0][0], y[0][1]);
+            epi_store8<EPI>(p, m, n + 64, y[1][0], y[1][1]);
         }
+    }
+    if (!more) break;
+    G256_PROLOGUE();
+  }
+#undef G256_PROLOGUE
 #undef G256_BAR
 #undef G256_LGKM8
 #undef G256_STAGE_A
@@ -586,7 +674,9 @@ int launch_epi(GemmArgs a, hipStream_t stream) {
     a.tiles_m = (a.M + 255) / 256;
     a.tiles_n = (a.N + 255) / 256;
     a.group_m = g_group_m > 0 ? g_group_m : 4;
-    hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(512), LDS_BYTES, stream, a);
+    const int tiles = a.tiles_m * a.tiles_n;
+    const int grid = (g_persist && tiles > g_num_cu) ? g_num_cu : tiles;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS_BYTES, stream, a);
     MMU_CHECK_LAUNCH();
     return 0;
 }
@@ -648,17 +738,20 @@ extern "C" int mmu_gemm_bf16_lora(int layout, const void* A, const void* B, void
     if (layout == 2 && (M & 7)) return -1;              // A stored [K][M]: chunks along M
     if (accumulate && (bias || resid || act)) return -1;
     if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) return -1;
-    GemmArgs a;
+    GemmArgs a = {};
     a.A = (const bf16*)A; a.B = (const bf16*)B; a.C = (bf16*)C;
     a.bias = (const bf16*)bias; a.resid = (const bf16*)resid;
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldr = ldr;
     a.act = act; a.accumulate = accumulate;
     a.lora_u = (const bf16*)lora_u; a.lora_b = (const bf16*)lora_b; a.lora_k = lora_k;
     a.rope_pos = g_rope.pos; a.rope_cos = g_rope.cos; a.rope_sin = g_rope.sin; a.rope_cols = g_rope.cols;
-    if (a.rope_pos && !pick_256(M, N, K)) return -2;  // fused RoPE exists in the 256^2 kernel only
+    // the 256^2 kernel's epilogue moves 16-B chunks of C / residual / bias
+    const bool use256 = pick_256(M, N, K) && !(ldc & 7) && !(resid && ((ldr & 7) || ((uintptr_t)resid & 15))) &&
+                        !(bias && ((uintptr_t)bias & 15));
+    if (a.rope_pos && !use256) return -2;  // fused RoPE exists in the 256^2 kernel only
     a.tiles_m = (M + BM - 1) / BM; a.tiles_n = (N + BN - 1) / BN;
     hipStream_t s = (hipStream_t)stream;
-    if (pick_256(M, N, K)) {
+    if (use256) {
         switch (layout) {
             case 0: return g256::launch<false, false>(a, s);
             case 1: return g256::launch<false, true>(a, s);
@@ -747,5 +840,11 @@ extern "C" int mmu_fold_f32_into_bf16(float* src32, void* dst, const void* mask,
     hipLaunchKernelGGL(fold_f32_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, src32, (bf16*)dst,
                        (const bf16*)mask, (size_t)n);
     MMU_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mmu_gemm_set_persistent(int mode) {
+    if (mode < 0 || mode > 1) return -1;
+    g_persist = mode;
     return 0;
 }

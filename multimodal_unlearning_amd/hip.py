@@ -28,6 +28,7 @@ SIGNATURES = {
     "mmu_fold_f32_into_bf16": [_vp, _vp, _vp, _ll, _vp],
     "mmu_gemm_set_tile": [_i],
     "mmu_gemm_set_group_m": [_i],
+    "mmu_gemm_set_persistent": [_i],
     "mmu_attn_fwd": [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp],
     "mmu_attn_bwd": [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i,
                      _vp],
@@ -77,6 +78,8 @@ def load() -> C.CDLL:
     """Load libmmu_hip.so; raises if it has not been built (python -m multimodal_unlearning_amd.build)."""
     global _lib
     if _lib is None:
+        global LIB_PATH
+        LIB_PATH = os.environ.get("MMU_HIP_LIB", LIB_PATH)  # A/B builds of the same ABI (tools/build_variant.py)
         if not os.path.exists(LIB_PATH):
             raise HipKernelError(
                 f"{LIB_PATH} not found: build it with `python -m multimodal_unlearning_amd.build` "
@@ -178,6 +181,10 @@ def gemm_splitk_accumulate(layout, A, B, c32, dst, mask=None, splits=16):
 
 def gemm_set_group_m(g: int):
     _check(load().mmu_gemm_set_group_m(int(g)), "mmu_gemm_set_group_m")
+
+
+def gemm_set_persistent(mode: int):
+    _check(load().mmu_gemm_set_persistent(int(mode)), "mmu_gemm_set_persistent")
 
 
 def gemm_set_tile(tile: int):

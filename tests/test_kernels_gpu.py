@@ -627,3 +627,34 @@ def test_clip_normalize_u8_matches_processor(dev):
     r = (u8.numpy().astype(np.float64) * (1 / 255)).astype(np.float32)
     ref = (r - np.array(C.OPENAI_CLIP_MEAN, np.float32).reshape(1, 3, 1, 1)) / np.array(C.OPENAI_CLIP_STD, np.float32).reshape(1, 3, 1, 1)
     assert np.array_equal(pv.cpu().numpy(), ref)
+
+
+def test_gemm256_persistent_launch_matches(dev):
+    """Persistent launch of the 256^2 kernel (256 workgroups walking 17x17 ragged tiles) == one workgroup per tile,
+    for the plain, bias+residual and accumulate epilogues (all through the swapped 16-B-store epilogue)."""
+    M, N, K = 4200, 4344, 328
+    A = _rand_int((M, K), dev, -2, 2, seed=11)
+    Bm = _rand_int((N, K), dev, -2, 2, seed=12)
+    bias = _rand_int((N,), dev, -3, 3, seed=13)
+    resid = _rand_int((M, N), dev, -3, 3, seed=14)
+    ref = A.float() @ Bm.float().t()
+    hip.gemm_set_tile(256)
+    try:
+        outs = []
+        for mode in (0, 1):
+            hip.gemm_set_persistent(mode)
+            c0 = torch.empty(M, N, device=dev, dtype=BF)
+            hip.gemm(hip.NT, A, Bm, c0)
+            c1 = torch.empty(M, N, device=dev, dtype=BF)
+            hip.gemm(hip.NT, A, Bm, c1, bias=bias, resid=resid)
+            c2 = resid.clone()
+            hip.gemm(hip.NT, A, Bm, c2, accumulate=True)
+            outs.append((c0, c1, c2))
+        for x, y in zip(*outs):
+            assert torch.equal(x, y)
+        assert torch.equal(outs[0][0], ref.to(BF))
+        assert torch.equal(outs[0][1], ((ref + bias.float()).to(BF).float() + resid.float()).to(BF))
+        assert torch.equal(outs[0][2], (ref + resid.float()).to(BF))
+    finally:
+        hip.gemm_set_persistent(0)
+        hip.gemm_set_tile(0)
