@@ -230,6 +230,7 @@ def main():
     ap.add_argument("--layers", type=int, default=0, help="debug: override decoder depth (invalidates the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gemm-persist", type=int, default=None, help="A/B: 256^2 GEMM launch mode (0 workgroup per tile, 1 persistent)")
+    ap.add_argument("--gemm-tail-split", type=int, default=None, help="A/B: split-K tail of the 256^2 GEMM (0 off, 1 heuristic = default)")
     ap.add_argument("--hbm-kernels", action="store_true",
                     help="also time the step's HBM-bound kernels standalone (bytes next to GB/s) after the timed region")
     ap.add_argument("--no-fuse", action="store_true")
@@ -245,6 +246,8 @@ def main():
     from multimodal_unlearning_amd.synthetic import bench_batch, make_forget_batch
     from multimodal_unlearning_amd.trainer import MMTrainerForgetting
 
+    if args.gemm_tail_split is not None:
+        hip.gemm_set_tail_split(args.gemm_tail_split)
     if args.gemm_persist is not None:
         hip.gemm_set_persistent(args.gemm_persist)
     rank, local, world = init_distributed()

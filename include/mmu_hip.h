@@ -55,6 +55,13 @@ int mmu_gemm_set_group_m(int group_m);
 /* 256x256 kernel launch mode (A/B tests): 0 = one workgroup per tile (default); 1 = persistent, 256 workgroups walk
  * the tiles. */
 int mmu_gemm_set_persistent(int mode);
+/* Split-K tail of the 256x256 kernel: when the last (tiles % 256) tiles fill at most half a round of the 256 CUs, each
+ * is cut into 256 / remainder K ranges on extra workgroups (fp32 partials in the workspace, reduced by a fold
+ * kernel) instead of occupying a whole round.  mode 0 off, 1 heuristic (default), 2 whenever applicable.  The caller
+ * registers a device workspace of >= mmu_gemm_workspace_bytes() (64 MiB); without one the tail split stays off. */
+int mmu_gemm_set_tail_split(int mode);
+int mmu_gemm_set_workspace(void* ws, long long bytes);
+long long mmu_gemm_workspace_bytes(void);
 
 /* ---- Attention (replaces the flash-attn wheel: mm/forget.py:86,98,106 attn_implementation=
  * "flash_attention_2"; SURVEY §8a K3 (CLIP, non-causal, head_dim 64) and K10 (Llama, causal, 128)) ----

@@ -29,6 +29,9 @@ static int g_force_tile = 0;  // mmu_gemm_set_tile
 static int g_group_m = 0;     // mmu_gemm_set_group_m
 static int g_persist = 0;     // mmu_gemm_set_persistent: 0 one workgroup per tile; 1 persistent (256 workgroups walk the tiles)
 static int g_num_cu = 256;    // MI355X
+static int g_tail_split = 1;     // mmu_gemm_set_tail_split: 0 off, 1 heuristic, 2 whenever the remainder is <= half a round
+static float* g_sk_ws = nullptr;  // mmu_gemm_set_workspace
+static size_t g_sk_ws_bytes = 0;
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -60,6 +63,13 @@ struct GemmArgs {
     // c32 [M][N] with atomics (tiny outputs only: skinny LoRA wgrads)
     float* c32;
     int kt_per_split;
+    // split-K tail (256^2 kernel): the last sk_tiles virtual tiles (ids >= sk_first), which would occupy a whole round
+    // of the 256 CUs, are each cut into sk_split equal K ranges handled by sk_tiles * sk_split extra workgroups
+    // (worker c: tile c / sk_split, range c % sk_split); partial accumulators go to sk_ws [worker][65536] fp32 and
+    // sk_fold_kernel reduces them.  Workers of one range index run the same K-tiles at the same time, so the tiles of
+    // a row / column still share their panels in L2 (a unit-balanced stream-K split loses that: measured 12 % slower).
+    int sk_tiles, sk_first, sk_split;
+    float* sk_ws;
 };
 
 __device__ __forceinline__ int swzT(int k) { return ((k & 3) << 1) | (((k >> 3) & 1) << 3); }
@@ -402,6 +412,59 @@ __device__ __forceinline__ void stage_half(char* dst, const StageDesc& d, int ld
     }
 }
 
+// Virtual tile id -> (m0, n0): bijective XCD-aware remap (virtual ids congruent mod 8 stay on one XCD, also in the
+// persistent launch where block b walks ids b, b + grid, ...), then GROUP_M rasterisation.
+__device__ __forceinline__ void decode_tile(const GemmArgs& p, int vt, int& m0, int& n0) {
+    const int total = p.tiles_m * p.tiles_n;
+    int pid = vt;
+    {
+        const int q = total >> 3, r = total & 7, xcd = pid & 7, loc = pid >> 3;
+        pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int per_group = p.group_m * p.tiles_n;
+    const int gid = pid / per_group;
+    const int first_m = gid * p.group_m;
+    const int gsz = min(p.tiles_m - first_m, p.group_m);
+    m0 = (first_m + (pid % per_group) % gsz) * 256;
+    n0 = ((pid % per_group) / gsz) * 256;
+}
+
+// Reduce the split-K partial accumulators of remainder tile r = blockIdx.x: C (+)= sum of its sk_split fp32 partials.  Workspace slot layout = the accumulator layout of the GEMM kernel:
+// [fragment (a,mt,b,nt)][wave][lane][4 consecutive columns].
+__global__ __launch_bounds__(256) void sk_fold_kernel(GemmArgs p, int accumulate) {
+    const int r = blockIdx.x;
+    const int nk = (p.K + 63) / 64;
+    const int kc = (nk + p.sk_split - 1) / p.sk_split;
+    int m0, n0;
+    decode_tile(p, p.sk_first + r, m0, n0);
+    for (int idx = blockIdx.y * 256 + threadIdx.x; idx < 16384; idx += gridDim.y * 256) {
+        f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < p.sk_split; ++i) {
+            if (i * kc >= nk) break;  // empty range: that worker wrote nothing
+            const int slot = r * p.sk_split + i;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(p.sk_ws + (size_t)slot * 65536 + (size_t)idx * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sum[j] += v[j];
+        }
+        const int frag = idx >> 9, wave = (idx >> 6) & 7, lane = idx & 63;
+        const int nt = frag & 1, b = (frag >> 1) & 1, mt = (frag >> 2) & 3, a = frag >> 4;
+        const int wm = wave >> 2, wn = wave & 3;
+        const int m = m0 + wm * 128 + a * 64 + mt * 16 + (lane & 15);
+        const int n = n0 + (wn >> 1) * 128 + b * 64 + (wn & 1) * 32 + nt * 16 + 4 * (lane >> 4);
+        if (m >= p.M || n >= p.N) continue;
+        bf16* cp = p.C + (size_t)m * p.ldc + n;
+        if (accumulate) {
+            const bf16x4 cv = *reinterpret_cast<const bf16x4*>(cp);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sum[j] += bf2f(cv[j]);
+        }
+        bf16x4 out;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) out[j] = f2bf(sum[j]);
+        *reinterpret_cast<bf16x4*>(cp) = out;
+    }
+}
+
 template <bool AT, bool BT, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -409,30 +472,26 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave >> 2, wn = wave & 3;
 
-    // Virtual tile id -> (m0, n0): bijective XCD-aware remap (virtual ids congruent mod 8 stay on one XCD, also in
-    // the persistent launch where block b walks ids b, b + grid, ...), then GROUP_M rasterisation.
     const int total_tiles = p.tiles_m * p.tiles_n;
-    auto decode = [&](int vt, int& m0_, int& n0_) {
-        int pid = vt;
-        {
-            const int nwg = total_tiles, q = nwg >> 3, r = nwg & 7, xcd = pid & 7, loc = pid >> 3;
-            pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-        }
-        const int GROUP_M = p.group_m;
-        const int per_group = GROUP_M * p.tiles_n;
-        const int gid = pid / per_group;
-        const int first_m = gid * GROUP_M;
-        const int gsz = min(p.tiles_m - first_m, GROUP_M);
-        m0_ = (first_m + (pid % per_group) % gsz) * 256;
-        n0_ = ((pid % per_group) / gsz) * 256;
-    };
+    const int nk = (p.K + 63) / 64;
+    // Work of this workgroup: whole tiles (vt, then vt + grid in the persistent launch), or — split-K worker — one K
+    // range [k0, k1) (in K-tiles) of one remainder tile.
+    const bool sk_worker = p.sk_tiles > 0 && (int)blockIdx.x >= p.sk_first;
+    int vt = blockIdx.x, k0 = 0, k1 = nk;
+    if (sk_worker) {
+        const int c = blockIdx.x - p.sk_first;
+        const int kc = (nk + p.sk_split - 1) / p.sk_split;
+        vt = p.sk_first + c / p.sk_split;
+        k0 = (c % p.sk_split) * kc;
+        k1 = min(nk, k0 + kc);
+        if (k0 >= k1) return;
+    }
 
     // LDS map: buffer d in {0,1}: [A-h0 | A-h1 | B-h0 | B-h1], 16 KiB each
     auto buf = [&](int d, int op, int h) -> char* { return smem + ((d * 2 + op) * 2 + h) * HB; };
 
-    int vt = blockIdx.x;
     int m0, n0;
-    decode(vt, m0, n0);
+    decode_tile(p, vt, m0, n0);
     StageDesc dA0 = make_desc<AT, true>(p.A, p.lda, m0, 0, p.M, wave, lane);
     StageDesc dA1 = make_desc<AT, true>(p.A, p.lda, m0, 1, p.M, wave, lane);
     StageDesc dB0 = make_desc<BT, false>(p.B, p.ldb, n0, 0, p.N, wave, lane);
@@ -442,8 +501,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     bf16x8 fa[2][4];     // [ks][mt]   current A block
     bf16x8 fb[2][2][2];  // [b][ks][nt]
 
-    const int nk = (p.K + 63) / 64;
-    const int niter = (nk + 1) / 2;
+    int kb = k0 * 64, klim = min(p.K, k1 * 64), niter = (k1 - k0 + 1) / 2;  // K window of the current segment
 
 #define G256_BAR()                               \
     do {                                         \
@@ -456,8 +514,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
         __builtin_amdgcn_sched_barrier(0);             \
         asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"); \
     } while (0)
-#define G256_STAGE_A(desc, d, h, kt) stage_half<AT>(buf(d, 0, h), desc, p.lda, (kt) * 64, p.K, wave)
-#define G256_STAGE_B(desc, d, h, kt) stage_half<BT>(buf(d, 1, h), desc, p.ldb, (kt) * 64, p.K, wave)
+#define G256_STAGE_A(desc, d, h, kt) stage_half<AT>(buf(d, 0, h), desc, p.lda, kb + (kt) * 64, klim, wave)
+#define G256_STAGE_B(desc, d, h, kt) stage_half<BT>(buf(d, 1, h), desc, p.ldb, kb + (kt) * 64, klim, wave)
 #define G256_READ_A(d, a)                                                                                  \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)    \
         fa[ks][mt] = read_frag<AT>((const MMU_LDS char*)buf(d, 0, a), wm * 64 + mt * 16, ks, lane)
@@ -563,7 +621,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     if (wm == 0) G256_BAR();  // balance the stagger barrier
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the overrun prefetches before the LDS is released
 
-    if (p.lora_k) {  // fused low-rank update: acc += U[M][kl] * BL[N][kl]^T
+    if (p.lora_k && k0 == 0) {  // fused low-rank update: acc += U[M][kl] * BL[N][kl]^T (once per tile)
         for (int ks = 0; ks < p.lora_k / 32; ++ks) {
             bf16x8 lu[2][4], lb[2][2];
 #pragma unroll
@@ -595,10 +653,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     // first counted wait of the next tile then also waits for the stores; a start skew between CUs costs more than
     // the store bursts it spreads; the persistent launch itself is worth < 0.2 % and is off by default.)
     const int cm0 = m0, cn0 = n0;
+    const bool partial = sk_worker;  // a K range of a remainder tile: fp32 partial to the workspace
+    const int slot = sk_worker ? (int)blockIdx.x - p.sk_first : 0;
     vt += gridDim.x;
-    const bool more = vt < total_tiles;
+    const bool more = p.sk_tiles == 0 && vt < total_tiles;  // persistent launch only
     if (more) {
-        decode(vt, m0, n0);
+        decode_tile(p, vt, m0, n0);
         dA0 = make_desc<AT, true>(p.A, p.lda, m0, 0, p.M, wave, lane);
         dA1 = make_desc<AT, true>(p.A, p.lda, m0, 1, p.M, wave, lane);
         dB0 = make_desc<BT, false>(p.B, p.ldb, n0, 0, p.N, wave, lane);
@@ -611,7 +671,20 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     // even rows of the nt=1 tile, after which a lane owns 8 consecutive columns (one 16-B store, 64-B runs per row):
     //   lane group g = lane>>4:  columns (g&1)*16 + (g>>1)*8 .. +7 of the wave's 32-column run.
     // b = 0 / 1 are swapped identically, so they stay the two halves (c, c + 64) of a RoPE pair.
-    {
+    if (partial) {
+        float* ws = p.sk_ws + (size_t)slot * 65536;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        const int frag = ((a * 4 + mt) * 2 + b) * 2 + nt;
+                        *reinterpret_cast<f32x4*>(ws + ((size_t)(frag * 8 + wave) * 64 + lane) * 4) = acc[a][b][nt][mt];
+                    }
+    } else {
     const int g4 = lane >> 4;
     const int cih = (wn & 1) * 32 + (g4 & 1) * 16 + (g4 >> 1) * 8;  // column inside the 128-wide group (< 64)
     const int n = cn0 + (wn >> 1) * 128 + cih;
@@ -675,6 +748,33 @@ int launch_epi(GemmArgs a, hipStream_t stream) {
     a.tiles_n = (a.N + 255) / 256;
     a.group_m = g_group_m > 0 ? g_group_m : 4;
     const int tiles = a.tiles_m * a.tiles_n;
+    // Split-K tail: with T tiles on 256 CUs the last T % 256 tiles occupy a whole round; when they are at most half a
+    // round, cut each into S = 256 / rem K ranges over rem * S extra workgroups (gate_up wgrad: 96 tiles x 2 ranges
+    // = 5.5 rounds instead of 6).  Plain / accumulate epilogues only (the fold kernel applies neither bias,
+    // activation, residual nor RoPE).
+    const int rem = tiles % g_num_cu;
+    const int nk = (a.K + 63) / 64;
+    int split = rem ? g_num_cu / rem : 0;
+    if (split > 8) split = 8;
+    if (split > nk) split = nk;
+    bool sk = g_tail_split && split >= 2 && EPI != 1 && !a.rope_pos && g_sk_ws &&
+              g_sk_ws_bytes >= (size_t)g_num_cu * 65536 * sizeof(float);
+    if (sk && g_tail_split == 1) {
+        const double saving_us = (1.0 - 1.0 / split) * nk * 1.45;  // measured us per K-tile of one tile
+        const double cost_us = 15.0 + 0.1 * rem * split;           // partial write + fold read at ~5 TB/s
+        sk = saving_us > 1.5 * cost_us;
+    }
+    if (sk) {
+        a.sk_tiles = rem;
+        a.sk_first = tiles - rem;
+        a.sk_split = split;
+        a.sk_ws = g_sk_ws;
+        hipLaunchKernelGGL(kern, dim3(a.sk_first + rem * split), dim3(512), LDS_BYTES, stream, a);
+        MMU_CHECK_LAUNCH();
+        hipLaunchKernelGGL(sk_fold_kernel, dim3(rem, 8), dim3(256), 0, stream, a, EPI == 2 ? 1 : 0);
+        MMU_CHECK_LAUNCH();
+        return 0;
+    }
     const int grid = (g_persist && tiles > g_num_cu) ? g_num_cu : tiles;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS_BYTES, stream, a);
     MMU_CHECK_LAUNCH();
@@ -848,3 +948,19 @@ extern "C" int mmu_gemm_set_persistent(int mode) {
     g_persist = mode;
     return 0;
 }
+
+// Split-K tail of the 256^2 kernel.  mode: 0 off, 1 when the model of saved rounds vs fold traffic says it pays
+// (default), 2 whenever the remainder tiles fill at most half a round (tests).  It needs a device workspace of at
+// least 256 * 256 KiB = 64 MiB registered with mmu_gemm_set_workspace (the library never allocates).
+extern "C" int mmu_gemm_set_tail_split(int mode) {
+    if (mode < 0 || mode > 2) return -1;
+    g_tail_split = mode;
+    return 0;
+}
+extern "C" int mmu_gemm_set_workspace(void* ws, long long bytes) {
+    if (bytes < 0 || ((uintptr_t)ws & 15)) return -1;
+    g_sk_ws = (float*)ws;
+    g_sk_ws_bytes = ws ? (size_t)bytes : 0;
+    return 0;
+}
+extern "C" long long mmu_gemm_workspace_bytes(void) { return (long long)g_num_cu * 65536 * sizeof(float); }

@@ -29,6 +29,8 @@ SIGNATURES = {
     "mmu_gemm_set_tile": [_i],
     "mmu_gemm_set_group_m": [_i],
     "mmu_gemm_set_persistent": [_i],
+    "mmu_gemm_set_tail_split": [_i],
+    "mmu_gemm_set_workspace": [_vp, _ll],
     "mmu_attn_fwd": [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp],
     "mmu_attn_bwd": [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i,
                      _vp],
@@ -185,6 +187,26 @@ def gemm_set_group_m(g: int):
 
 def gemm_set_persistent(mode: int):
     _check(load().mmu_gemm_set_persistent(int(mode)), "mmu_gemm_set_persistent")
+
+
+def gemm_set_tail_split(mode: int):
+    _check(load().mmu_gemm_set_tail_split(int(mode)), "mmu_gemm_set_tail_split")
+
+
+_gemm_ws = None
+
+
+def ensure_gemm_workspace(device):
+    """Register the 64 MiB device workspace the split-K tail of the 256^2 GEMM needs (one per process = per GPU)."""
+    global _gemm_ws
+    if _gemm_ws is None or _gemm_ws.device != torch.device(device):
+        lib = load()
+        lib.mmu_gemm_workspace_bytes.restype = C.c_longlong
+        lib.mmu_gemm_workspace_bytes.argtypes = []
+        n = int(lib.mmu_gemm_workspace_bytes())
+        _gemm_ws = torch.empty(n, device=device, dtype=torch.uint8)
+        _check(lib.mmu_gemm_set_workspace(_p(_gemm_ws), n), "mmu_gemm_set_workspace")
+    return _gemm_ws
 
 
 def gemm_set_tile(tile: int):

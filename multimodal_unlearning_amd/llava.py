@@ -203,6 +203,8 @@ class LlavaHIP(nn.Module):
         self.transposed_wgrad = True
         self.transposed_wgrad_min_m = 1024
         self.fuse_rope = os.environ.get("MMU_NO_ROPE_FUSION", "0") != "1"  # A/B switch
+        if torch.device(device).type == "cuda":
+            hip.ensure_gemm_workspace(torch.device(device))  # split-K tail partials (128 MiB, once per process)
         self.lora_splitk_min_m = 2048
         if params is not None:
             self.load_params(params)

@@ -658,3 +658,40 @@ def test_gemm256_persistent_launch_matches(dev):
     finally:
         hip.gemm_set_persistent(0)
         hip.gemm_set_tile(0)
+
+
+@pytest.mark.parametrize("layout", [hip.NT, hip.NN, hip.TN])
+@pytest.mark.parametrize("shape", [(4200, 4344, 2048), (1000, 1096, 520), (2304, 4096, 8192 + 64), (256 * 7, 256 * 5, 192)])
+def test_gemm256_split_tail_matches(dev, layout, shape):
+    """Split-K tail (remainder tiles cut into K-tile units over 256 workers + fold) == the plain launch, bit for bit on
+    integer data, for the store and accumulate epilogues and the fused low-rank term (added by the k0 == 0 segment)."""
+    M, N, K = shape
+    hip.ensure_gemm_workspace(dev)
+    a = _rand_int((M, K), dev, -2, 2, seed=21)
+    b = _rand_int((N, K), dev, -2, 2, seed=22)
+    A = a if layout != hip.TN else a.t().contiguous()
+    Bm = b if layout == hip.NT else b.t().contiguous()
+    c_init = _rand_int((M, N), dev, -3, 3, seed=23)
+    U = _rand_int((M, 32), dev, -1, 1, seed=24)
+    BL = _rand_int((N, 32), dev, -1, 1, seed=25)
+    hip.gemm_set_tile(256)
+    try:
+        res = []
+        for mode in (0, 2):
+            hip.gemm_set_tail_split(mode)
+            c0 = torch.empty(M, N, device=dev, dtype=BF)
+            hip.gemm(layout, A, Bm, c0)
+            c1 = c_init.clone()
+            hip.gemm(layout, A, Bm, c1, accumulate=True)
+            c2 = torch.empty(M, N, device=dev, dtype=BF)
+            hip.gemm(layout, A, Bm, c2, lora_u=U, lora_b=BL)
+            res.append((c0, c1, c2))
+        for x, y in zip(*res):
+            assert torch.equal(x, y)
+        ref = a.float() @ b.float().t()
+        assert torch.equal(res[1][0], ref.to(BF))
+        assert torch.equal(res[1][1], (ref + c_init.float()).to(BF))
+        assert torch.equal(res[1][2], (ref + U.float() @ BL.float().t()).to(BF))
+    finally:
+        hip.gemm_set_tail_split(1)
+        hip.gemm_set_tile(0)
