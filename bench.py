@@ -231,6 +231,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gemm-persist", type=int, default=None, help="A/B: 256^2 GEMM launch mode (0 workgroup per tile, 1 persistent)")
     ap.add_argument("--gemm-tail-split", type=int, default=None, help="A/B: split-K tail of the 256^2 GEMM (0 off, 1 heuristic = default)")
+    ap.add_argument("--keep-act-t", type=int, default=None, help="keep act^T from forward to backward (default: on when it costs <= 24 GB)")
     ap.add_argument("--hbm-kernels", action="store_true",
                     help="also time the step's HBM-bound kernels standalone (bytes next to GB/s) after the timed region")
     ap.add_argument("--no-fuse", action="store_true")
@@ -274,6 +275,9 @@ def main():
                        transposed_weights=not args.no_wt)
 
     B, GA = args.micro_batch, args.grad_accum
+    n_seq = B * (2 if (len(splits) >= 2 and not args.no_fuse and args.loss.lower() in ("grad_diff_forget_ce_retain_ce", "eco_ft", "idk")) else 1)
+    act_t_bytes = n_seq * (cfg.vision.num_patches + 512) * cfg.text.intermediate_size * 2 * cfg.text.num_layers
+    model.keep_act_t = bool(args.keep_act_t) if args.keep_act_t is not None else (args.model == "7b" and act_t_bytes <= 24e9)
     if args.model == "tiny":
         S = 64
         mbs = [make_forget_batch(cfg, B, S, seed=1234 + rank * 100 + i, n_question=8, splits=splits, device=dev)
@@ -340,6 +344,7 @@ def main():
                                    f"tokens), image 336, random-init weights", "micro_batch_pairs_per_gpu": B,
                        "grad_accum": GA, "global_batch": world * B * GA, "seq_len": S, "parallelism": f"dp{world}",
                        "paired_fusion": not args.no_fuse, "optimizer": "AdamW fp32 moments, clip 1.0", "lora_r": args.lora_r,
+                       "keep_act_t": model.keep_act_t,
                        "decoder_layers": cfg.text.num_layers},
             "step_tflops_per_gpu": round(value * fps / world / 1e12, 1),
             "step_frac_of_mfma_peak": round(value * fps / world / PEAK_BF16, 4),

@@ -113,6 +113,9 @@ int mmu_transpose_bf16(const void* src, void* dst, int R, int C, void* stream);
 /* Fused producers of TRANSPOSED wgrad operands (the NT wgrad path reads X^T / dY^T): SwiGLU recompute -> act^T
  * [I][M]; RMSNorm recompute from the saved rstd -> y^T [d][M]; SwiGLU backward -> dgu [M][2I] and dgu^T [2I][M]. */
 int mmu_swiglu_fwd_t(const void* gate_up, void* actT, int M, int I, void* stream);
+/* Forward SwiGLU that writes act [M][I] and act^T [I][M] in one pass (act^T kept for the down-proj wgrad instead of
+ * being recomputed in backward: +M*I*2 B of HBM per layer, one read of gate|up less). */
+int mmu_swiglu_fwd_both(const void* gate_up, void* act, void* actT, int M, int I, void* stream);
 int mmu_rmsnorm_apply_t(const void* x, const void* w, const float* rstd, void* yT, int M, int d, void* stream);
 int mmu_swiglu_bwd_t(const void* gate_up, const void* dh, void* dgate_up, void* dgate_upT, int M, int I, void* stream);
 int mmu_colsum_nparts(int M); /* part must hold nparts*d floats */

@@ -563,6 +563,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16* __restrict__
 // MODE 0: act^T  = (bf16(silu(g)) * u)^T              from gate|up [M][2I]            (SwiGLU recompute in backward)
 // MODE 1: y^T    = (w * bf16(x * rstd))^T             from x [M][d], w [d], rstd [M]   (RMSNorm recompute in backward)
 // MODE 2: dgu and dgu^T from gate|up and dh           (SwiGLU backward: both layouts are consumed)
+// MODE 3: act and act^T from gate|up                  (SwiGLU forward that also leaves the down-proj wgrad operand)
 // R rows (tokens), C columns of the OUTPUT of the elementwise op; R % 8 == 0, C % 8 == 0.
 // ------------------------------------------------------------------------------------------------
 template <int MODE>
@@ -579,7 +580,7 @@ __global__ __launch_bounds__(256) void fused_t_kernel(const bf16* __restrict__ i
 #pragma unroll
         for (int j = 0; j < 8; ++j) { o0[j] = f2bf(0.f); o1[j] = f2bf(0.f); }
         if (r < R && c < C) {
-            if (MODE == 0) {
+            if (MODE == 0 || MODE == 3) {
                 const bf16x8 g = *reinterpret_cast<const bf16x8*>(in0 + (size_t)r * 2 * C + c);
                 const bf16x8 u = *reinterpret_cast<const bf16x8*>(in0 + (size_t)r * 2 * C + C + c);
 #pragma unroll
@@ -587,6 +588,7 @@ __global__ __launch_bounds__(256) void fused_t_kernel(const bf16* __restrict__ i
                     const float gf = bf2f(g[j]);
                     o0[j] = f2bf(round_bf16(gf / (1.0f + __expf(-gf))) * bf2f(u[j]));
                 }
+                if (MODE == 3) *reinterpret_cast<bf16x8*>(out_n + (size_t)r * C + c) = o0;
             } else if (MODE == 1) {
                 const bf16x8 x = *reinterpret_cast<const bf16x8*>(in0 + (size_t)r * C + c);
                 const bf16x8 w = *reinterpret_cast<const bf16x8*>(in1 + c);
@@ -859,6 +861,14 @@ extern "C" int mmu_swiglu_fwd_t(const void* gu, void* actT, int M, int I, void* 
     if (M <= 0 || (I & 7) || (M & 7)) return -1;
     hipLaunchKernelGGL(fused_t_kernel<0>, dim3((I + 63) / 64, (M + 63) / 64), dim3(256), 0, (hipStream_t)stream,
                        (const bf16*)gu, (const bf16*)nullptr, (const float*)nullptr, (bf16*)nullptr, (bf16*)actT, M, I);
+    MMU_CHECK_LAUNCH();
+    return 0;
+}
+// act [M][I] and act^T [I][M] in one pass over gate|up (forward; act^T is kept for the down-proj wgrad)
+extern "C" int mmu_swiglu_fwd_both(const void* gu, void* act, void* actT, int M, int I, void* stream) {
+    if (M <= 0 || (I & 7) || (M & 7)) return -1;
+    hipLaunchKernelGGL(fused_t_kernel<3>, dim3((I + 63) / 64, (M + 63) / 64), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16*)gu, (const bf16*)nullptr, (const float*)nullptr, (bf16*)act, (bf16*)actT, M, I);
     MMU_CHECK_LAUNCH();
     return 0;
 }

@@ -52,6 +52,7 @@ SIGNATURES = {
     "mmu_add_bf16": [_vp, _vp, _vp, _ll, _vp],
     "mmu_transpose_bf16": [_vp, _vp, _i, _i, _vp],
     "mmu_swiglu_fwd_t": [_vp, _vp, _i, _i, _vp],
+    "mmu_swiglu_fwd_both": [_vp, _vp, _vp, _i, _i, _vp],
     "mmu_rmsnorm_apply_t": [_vp, _vp, _vp, _vp, _i, _i, _vp],
     "mmu_swiglu_bwd_t": [_vp, _vp, _vp, _vp, _i, _i, _vp],
     "mmu_colsum_nparts": [_i],
@@ -348,6 +349,12 @@ def swiglu_fwd_t(gu, actT):
     M, I2 = gu.shape
     _check(load().mmu_swiglu_fwd_t(_p(gu), _p(actT), M, I2 // 2, _stream()), "mmu_swiglu_fwd_t")
     return actT
+
+
+def swiglu_fwd_both(gu, act, actT):
+    _bf16c(gu, act, actT)
+    M, I2 = gu.shape
+    _check(load().mmu_swiglu_fwd_both(_p(gu), _p(act), _p(actT), M, I2 // 2, _stream()), "mmu_swiglu_fwd_both")
 
 
 def rmsnorm_apply_t(x, w, rstd, yT):

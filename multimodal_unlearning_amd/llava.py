@@ -203,6 +203,9 @@ class LlavaHIP(nn.Module):
         self.transposed_wgrad = True
         self.transposed_wgrad_min_m = 1024
         self.fuse_rope = os.environ.get("MMU_NO_ROPE_FUSION", "0") != "1"  # A/B switch
+        # keep act^T of every layer from forward to backward (+ layers*M*I*2 B, 23 GB at 7B / 30 sequences) instead of
+        # recomputing it from gate|up in backward; the owner of the step turns it on when HBM allows (bench.py does)
+        self.keep_act_t = False
         if torch.device(device).type == "cuda":
             hip.ensure_gemm_workspace(torch.device(device))  # split-K tail partials (128 MiB, once per process)
         self.lora_splitk_min_m = 2048
@@ -670,11 +673,16 @@ class LlavaHIP(nn.Module):
             gu = torch.empty(M, 2 * I, device=dev, dtype=BF)
             self._lin_fwd(p + "gate_up.weight", y, gu)
             act = torch.empty(M, I, device=dev, dtype=BF)
-            hip.swiglu_fwd(gu, act)
+            actT = None
+            if save and self.keep_act_t and self._use_t(M):
+                actT = torch.empty(I, M, device=dev, dtype=BF)  # the down-proj wgrad operand, kept until backward
+                hip.swiglu_fwd_both(gu, act, actT)
+            else:
+                hip.swiglu_fwd(gu, act)
             hn = torch.empty(M, dt, device=dev, dtype=BF)
             self._lin_fwd(p + "down.weight", act, hn, resid=h2)
             if save:
-                saved["layers"].append((h, rstd1, qkv, a, lse, h2, rstd2, gu))
+                saved["layers"].append((h, rstd1, qkv, a, lse, h2, rstd2, gu, actT))
             h = hn
             if self.capture_layer is not None and i == self.capture_layer:
                 self._last_capture = h.view(B, S, dt)
@@ -735,14 +743,15 @@ class LlavaHIP(nn.Module):
         layers = saved["layers"]
         for i in reversed(range(top + 1)):
             p = f"text.layers.{i}."
-            hin, rstd1, qkv, a, lse, h2, rstd2, gu = layers[i]
+            hin, rstd1, qkv, a, lse, h2, rstd2, gu, actT = layers[i]
             layers[i] = None
             # MLP
             dact = torch.empty(M, I, device=dev, dtype=BF)
             dgu = torch.empty(M, 2 * I, device=dev, dtype=BF)
             if use_t:  # wgrad operands come out of their producers already transposed
-                actT = torch.empty(I, M, device=dev, dtype=BF)
-                hip.swiglu_fwd_t(gu, actT)
+                if actT is None:
+                    actT = torch.empty(I, M, device=dev, dtype=BF)
+                    hip.swiglu_fwd_t(gu, actT)
                 self._wgrad_t(dh, None, actT, p + "down.weight")
                 self._dgrad(dh, p + "down.weight", dact)
                 del actT

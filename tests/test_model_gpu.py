@@ -482,3 +482,26 @@ def test_lora_merge_and_adapter_io(dev, tmp_path):
     with torch.no_grad():
         again = plain.logits(sp["input_ids"], sp["attention_mask"], sp["pixel_values"]).float()
     assert torch.equal(again, after)
+
+
+def test_keep_act_t_is_equivalent(dev):
+    """Keeping act^T from the forward (one fused SwiGLU pass writing act and act^T) gives the same loss and gradients,
+    bit for bit, as recomputing act^T from gate|up in backward."""
+    from multimodal_unlearning_amd.llava import LlavaHIP
+    from multimodal_unlearning_amd.trainer import MMTrainerForgetting
+
+    cfg = tiny_test_config()
+    model = LlavaHIP(cfg, init_params(cfg, seed=0), device=dev)
+    model.transposed_wgrad_min_m = 0
+    inputs = make_forget_batch(cfg, 2, 64, seed=29, n_question=9)
+    tr = MMTrainerForgetting(model=model, forget_loss="grad_diff_forget_ce_retain_ce", teacher_model=None, loss_beta=1.0,
+                             l1_lambda=0, l0_lambda=0, l_norm_from="zero")
+    res = []
+    for keep in (False, True):
+        model.keep_act_t = keep
+        model.ensure_grad().zero_()
+        loss = tr.compute_loss(model, inputs)
+        loss.backward()
+        res.append((float(loss), model.ensure_grad().clone()))
+    assert res[0][0] == res[1][0]
+    assert torch.equal(res[0][1], res[1][1])
