@@ -55,6 +55,7 @@ class GemmTimer:
     def __init__(self, hipmod):
         self.hip = hipmod
         self.orig = hipmod.gemm
+        self.orig_rope = hipmod.gemm_rope
         self.records = []
 
     def __enter__(self):
@@ -77,11 +78,24 @@ class GemmTimer:
             self.records.append((layout, m, n, k, e0, e1, bool(kw.get("accumulate")), kw.get("resid") is not None))
             return r
 
+        def timed_rope(x, w, out, *a, **kw):  # the q|k|v projection with the fused RoPE epilogue (same kernel)
+            s = torch.cuda.current_stream()
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record(s)
+            launched = self.orig_rope(x, w, out, *a, **kw)
+            e1.record(s)
+            if launched:
+                self.records.append((self.hip.NT, x.shape[0], w.shape[0], x.shape[1], e0, e1, False, False))
+            return launched
+
         self.hip.gemm = timed
+        self.hip.gemm_rope = timed_rope
         return self
 
     def __exit__(self, *a):
         self.hip.gemm = self.orig
+        self.hip.gemm_rope = self.orig_rope
 
     def summary(self):
         torch.cuda.synchronize()
