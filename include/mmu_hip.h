@@ -148,6 +148,12 @@ int mmu_rowloss_fwd(int mode, const void* slog, const void* tlog, int ldv, float
 int mmu_rowloss_bwd(int mode, const void* slog, const void* tlog, int ldv, float beta, const float* stats,
                     const float* coef, void* dlogits, int ldd, int M, int V, void* stream);
 
+/* ---- L1 / L0 regulariser of compute_loss (mm/trainer.py:451-481: torch.norm(cat(param - teacher_param), p=1 | 0)) over
+ * the flat trainable buffer: d = bf16(p - t) (t = NULL: d = p); out2[0] += sum|d|, out2[1] += #(d != 0) in fp64.
+ * Backward: g += lambda1 * *gout * sign(d) (gout: device scalar = upstream gradient, NULL = 1; L0 has no gradient). */
+int mmu_l1l0_fwd(const void* p, const void* t, long long n, double* out2, void* stream);
+int mmu_l1_bwd(const void* p, const void* t, long long n, void* g, float lambda1, const float* gout, void* stream);
+
 /* ---- Optimiser step after compute_loss (HF loop: clip_grad_norm_ -> AdamW -> zero_grad; mm/forget.py:139-168) ---- */
 int mmu_sumsq_bf16(const void* g, long long n, float* out_sumsq, void* stream);
 int mmu_adamw_bf16(void* p, void* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,

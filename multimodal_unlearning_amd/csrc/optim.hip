@@ -24,6 +24,52 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const bf16* __restrict__ g, 
     if (threadIdx.x == 0) atomicAdd(out, s);
 }
 
+// L1 / L0 "norm" of d = bf16(p - t) (t = null: d = p): out[0] += sum |d|, out[1] += #(d != 0)  (fp64 accumulators).
+// mm/trainer.py:451-481 builds torch.cat of every (param - teacher_param) and calls torch.norm(p=1 / p=0) on it: a
+// 13.5 GB temporary at 7B; here it is one streaming pass over the two flat buffers.
+__global__ __launch_bounds__(256) void l1l0_fwd_kernel(const bf16* __restrict__ p, const bf16* __restrict__ t, size_t n8,
+                                                       double* __restrict__ out) {
+    __shared__ float scratch[4];
+    float s = 0.f, c = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(p + i * 8);
+        bf16x8 b;
+        if (t) b = *reinterpret_cast<const bf16x8*>(t + i * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float d = t ? round_bf16(bf2f(a[j]) - bf2f(b[j])) : bf2f(a[j]);
+            s += fabsf(d);
+            c += d != 0.f ? 1.f : 0.f;
+        }
+    }
+    s = block_sum<4>(s, scratch);
+    __syncthreads();
+    c = block_sum<4>(c, scratch);
+    if (threadIdx.x == 0) {
+        atomicAdd(out, (double)s);
+        atomicAdd(out + 1, (double)c);
+    }
+}
+
+// g += (lambda1 * *gout) * sign(bf16(p - t))   (the L0 term has zero gradient, as torch.norm(p=0) does)
+__global__ __launch_bounds__(256) void l1_bwd_kernel(const bf16* __restrict__ p, const bf16* __restrict__ t, size_t n8,
+                                                     bf16* __restrict__ g, float lambda1, const float* __restrict__ gout) {
+    const float coef = lambda1 * (gout ? *gout : 1.f);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(p + i * 8);
+        bf16x8 b;
+        if (t) b = *reinterpret_cast<const bf16x8*>(t + i * 8);
+        bf16x8 gv = *reinterpret_cast<const bf16x8*>(g + i * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float d = t ? round_bf16(bf2f(a[j]) - bf2f(b[j])) : bf2f(a[j]);
+            const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+            gv[j] = f2bf(bf2f(gv[j]) + coef * sg);
+        }
+        *reinterpret_cast<bf16x8*>(g + i * 8) = gv;
+    }
+}
+
 struct AdamArgs {
     bf16* p;
     bf16* g;
@@ -95,6 +141,29 @@ extern "C" int mmu_sumsq_bf16(const void* g, long long n, float* out_sumsq, void
     size_t grid = (n8 + 255) / 256;
     if (grid > 2048) grid = 2048;
     hipLaunchKernelGGL(sumsq_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)g, n8, out_sumsq);
+    MMU_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mmu_l1l0_fwd(const void* p, const void* t, long long n, double* out2, void* stream) {
+    if (n <= 0 || (n & 7) || !out2) return -1;
+    const size_t n8 = (size_t)n / 8;
+    size_t grid = (n8 + 255) / 256;
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(l1l0_fwd_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)p, (const bf16*)t,
+                       n8, out2);
+    MMU_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mmu_l1_bwd(const void* p, const void* t, long long n, void* g, float lambda1, const float* gout,
+                          void* stream) {
+    if (n <= 0 || (n & 7) || !g) return -1;
+    const size_t n8 = (size_t)n / 8;
+    size_t grid = (n8 + 255) / 256;
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(l1_bwd_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)p, (const bf16*)t,
+                       n8, (bf16*)g, lambda1, gout);
     MMU_CHECK_LAUNCH();
     return 0;
 }

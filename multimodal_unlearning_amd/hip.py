@@ -65,6 +65,8 @@ SIGNATURES = {
     "mmu_seg_reduce": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp],
     "mmu_rowloss_fwd": [_i, _vp, _vp, _i, _f, _vp, _i, _i, _vp],
     "mmu_rowloss_bwd": [_i, _vp, _vp, _i, _f, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "mmu_l1l0_fwd": [_vp, _vp, _ll, _vp, _vp],
+    "mmu_l1_bwd": [_vp, _vp, _ll, _vp, _f, _vp, _vp],
     "mmu_sumsq_bf16": [_vp, _ll, _vp, _vp],
     "mmu_adamw_bf16": [_vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _f, _i, _vp, _f, _f, _i, _vp],
     "mmu_scale_bf16": [_vp, _ll, _f, _vp],
@@ -442,6 +444,19 @@ def rowloss_bwd(mode, slog, tlog, beta, stats, coef, dlogits):
 
 
 # ---------------------------------------------------------------------------------------------- optimiser
+def l1l0_fwd(p, t, out2):
+    """out2 (float64[2], zeroed by the caller) += [sum |bf16(p - t)|, #(bf16(p - t) != 0)]; t may be None."""
+    _bf16c(p, t)
+    assert out2.dtype == torch.float64 and out2.numel() == 2 and (t is None or t.numel() == p.numel())
+    _check(load().mmu_l1l0_fwd(_p(p), _p(t), p.numel(), _p(out2), _stream()), "mmu_l1l0_fwd")
+
+
+def l1_bwd(p, t, g, lambda1, gout):
+    _bf16c(p, t, g)
+    assert gout is None or (gout.dtype == torch.float32 and gout.numel() == 1)
+    _check(load().mmu_l1_bwd(_p(p), _p(t), p.numel(), _p(g), float(lambda1), _p(gout), _stream()), "mmu_l1_bwd")
+
+
 def sumsq(g, out):
     _bf16c(g)
     _check(load().mmu_sumsq_bf16(_p(g), g.numel(), _p(out), _stream()), "mmu_sumsq_bf16")

@@ -27,6 +27,31 @@ from .llava import segment_ce_losses
 _SPLIT_KEYS = ("input_ids", "attention_mask", "pixel_values", "labels")
 
 
+class _L1L0Fn(torch.autograd.Function):
+    """reg = l1 * ||d||_1 + l0 * ||d||_0 with d = bf16(flat - teacher_flat) (or flat), mm/trainer.py:451-481, as HIP
+    kernels over the flat buffers.  backward() accumulates l1 * g * sign(d) into the model's flat gradient buffer and
+    returns no tensor for it (same convention as the model's autograd edge)."""
+
+    @staticmethod
+    def forward(ctx, flat, model, tflat, l1, l0):
+        from . import hip
+
+        out = torch.zeros(2, device=flat.device, dtype=torch.float64)
+        hip.l1l0_fwd(flat.detach(), tflat, out)
+        ctx.model, ctx.tflat, ctx.l1 = model, tflat, l1
+        return (l1 * out[0] + l0 * out[1]).float()
+
+    @staticmethod
+    def backward(ctx, gout):
+        from . import hip
+
+        if ctx.l1:
+            model = ctx.model
+            g = model.ensure_grad()
+            hip.l1_bwd(model.train_flat.detach(), ctx.tflat, g, ctx.l1, gout.detach().float().reshape(1).contiguous())
+        return None, None, None, None, None
+
+
 class MMTrainerForgetting:
     def __init__(self, *args, **kwargs):
         self.loss_type = kwargs.pop("forget_loss").lower()
@@ -247,6 +272,16 @@ class MMTrainerForgetting:
             if lora:
                 raise ValueError("L1\\L0 regularization is not supported for LORA!")
             params = [p.view(-1) for p in model.parameters() if p.requires_grad]
+        flat = getattr(model, "train_flat", None)
+        if flat is not None and flat.is_cuda and len(params) == 1:
+            # LlavaHIP: one streaming HIP pass over the flat trainable buffer (and the teacher's) instead of a
+            # 13.5 GB torch.cat temporary; the backward adds lambda1 * sign(d) straight into the flat gradient
+            tflat = None
+            if self.l_norm_from == "init" and not lora:
+                tflat = next(iter(self.teacher_model.parameters())).detach()
+                if tflat.device != flat.device:
+                    tflat = tflat.to(flat.device)
+            return _L1L0Fn.apply(flat, model, tflat, float(l1 or 0.0), float(l0 or 0.0))
         reg = 0.0
         cat = torch.cat(params).float()
         if l1 is not None and l1 != 0:

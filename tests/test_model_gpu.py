@@ -505,3 +505,25 @@ def test_keep_act_t_is_equivalent(dev):
         res.append((float(loss), model.ensure_grad().clone()))
     assert res[0][0] == res[1][0]
     assert torch.equal(res[0][1], res[1][1])
+
+
+def test_l1l0_regulariser_hip_kernels(models):
+    """mm/trainer.py:451-481 through the HIP kernels: value == torch.norm(p=1/0) of bf16(p - teacher) (fp64 reference),
+    gradient == lambda1 * upstream * sign(d) accumulated into the flat gradient (exact in bf16), L0 without gradient."""
+    from multimodal_unlearning_amd.trainer import MMTrainerForgetting
+
+    cfg, P, student, teacher = models
+    p = student.train_flat.detach()
+    tflat = next(iter(teacher.parameters())).detach()
+    for frm, t in (("init", tflat), ("zero", None)):
+        tr = MMTrainerForgetting(model=student, forget_loss="grad_ascent", teacher_model=teacher, loss_beta=1.0,
+                                 l1_lambda=0.25, l0_lambda=0.5, l_norm_from=frm, loss_args={})
+        d = (p - t) if t is not None else p
+        ref = 0.25 * d.double().abs().sum() + 0.5 * (d != 0).double().sum()
+        student.ensure_grad().zero_()
+        reg = tr._l_norm_regulariser(student)
+        assert abs(float(reg) - float(ref)) <= 1e-6 * abs(float(ref)), (frm, float(reg), float(ref))
+        (reg * 0.5).backward()
+        want = (0.25 * 0.5 * torch.sign(d.float())).to(torch.bfloat16)
+        assert torch.equal(student.ensure_grad(), want), frm
+    student.ensure_grad().zero_()
