@@ -52,6 +52,39 @@ __device__ __forceinline__ void stage_rows(char* tile, const bf16* __restrict__ 
     }
 }
 
+// The same staging with the per-lane part of the address (row * ld + swizzled chunk) computed ONCE: per tile only a
+// wave-uniform base pointer moves, and full tiles skip the per-lane bounds select (the per-block address arithmetic of
+// stage_rows was ~150 issue slots in front of every block's MFMAs).
+template <int D, int KIND, int R, int NW = 4>
+struct RowStager {
+    static constexpr int ROWB = D * 2, RPI = 1024 / ROWB, CPR = ROWB / 16, NI = R / RPI, PW = NI / NW;
+    int off[PW];  // elements from the tile's first row
+    int row[PW];
+    __device__ __forceinline__ void init(int ld, int wave, int lane) {
+#pragma unroll
+        for (int i = 0; i < PW; ++i) {
+            const int t = wave * PW + i;
+            const int r = t * RPI + lane / CPR;
+            const int c = (lane % CPR) ^ swz<D, KIND>(r);
+            row[i] = r;
+            off[i] = r * ld + c * 8;
+        }
+    }
+    __device__ __forceinline__ void issue(char* tile, const bf16* __restrict__ g, int ld, int row0, int row_limit,
+                                          int wave) const {
+        const bf16* base = g + (size_t)row0 * ld;
+        if (row0 + R <= row_limit) {
+#pragma unroll
+            for (int i = 0; i < PW; ++i) glds16(base + off[i], tile + (wave * PW + i) * 1024);
+        } else {
+            const bf16* zero = reinterpret_cast<const bf16*>(mmu_zero16);
+#pragma unroll
+            for (int i = 0; i < PW; ++i)
+                glds16((row0 + row[i] < row_limit) ? base + off[i] : zero, tile + (wave * PW + i) * 1024);
+        }
+    }
+};
+
 // Row-read fragment: lane l gets tile[base + (l&31)][16*ks + 8*(l>>5) + 0..7]
 template <int D, int KIND>
 __device__ __forceinline__ bf16x8 row_frag(const MMU_LDS char* tile, int base, int ks, int lane) {
@@ -176,6 +209,28 @@ struct AttnArgs {
 // Forward. grid (ceil(S/128), H, B), 256 threads; wave w owns query rows qb*128 + 32w .. +31.
 // LDS: 2 x (K tile 64xD | V tile 64xD) + 2 x 64 floats key bias.
 // ------------------------------------------------------------------------------------------------
+// Workgroup -> (tile, head, batch) for a 1-D grid of nx * H * B workgroups.  The hardware deals consecutive workgroup
+// ids round-robin over the 8 XCDs (each with its own L2), so with the natural order the nx tiles of one (batch, head)
+// — which all stream the same K / V (or Q / dO) rows — land on 8 different L2s and every one of them fetches that
+// head again.  Here the XCD index (id & 7) selects the (batch, head) pair inside a group of 8 pairs and the remaining
+// bits walk that pair's tiles, so one head's tiles run back to back on ONE XCD and hit in its L2.  Heavy (late, causal)
+// tiles first.  Falls back to the natural order when H * B is not a multiple of 8.
+__device__ __forceinline__ void decode_wg(int nx, int H, int B, bool heavy_is_last, int& tile, int& hh, int& b) {
+    const int w = blockIdx.x, nbh = H * B;
+    int bh, t;
+    if ((nbh & 7) == 0) {
+        const int xcd = w & 7, slot = w >> 3;
+        bh = (slot / nx) * 8 + xcd;
+        t = slot % nx;
+    } else {
+        bh = w / nx;
+        t = w % nx;
+    }
+    tile = heavy_is_last ? nx - 1 - t : t;  // causal: late query tiles / early key tiles carry the most blocks
+    hh = bh % H;
+    b = bh / H;
+}
+
 template <int D, bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -184,7 +239,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int hl = lane >> 5;
-    const int qb = blockIdx.x, hh = blockIdx.y, b = blockIdx.z;
+    int qb, hh, b;
+    decode_wg((a.S + 127) / 128, a.H, a.B, true, qb, hh, b);
     const int S = a.S;
     const size_t rowbase = (size_t)b * S;
     const bf16* qp = a.q + rowbase * a.ld + hh * D;
@@ -216,11 +272,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     const int kv_end = CAUSAL ? min(S, qb * 128 + 128) : S;
     const int nblk = (kv_end + 63) / 64;
 
+    RowStager<D, KIND_ROW, 64> st_k;
+    RowStager<D, KIND_TR, 64> st_v;
+    st_k.init(a.ld, wave, lane);
+    st_v.init(a.ld, wave, lane);
     auto stage = [&](int kb, int buf) {
         char* base = smem + buf * 2 * TB;
-        stage_rows<D, KIND_ROW, 64>(base, kp, a.ld, kb * 64, S, wave, lane);
-        stage_rows<D, KIND_TR, 64>(base + TB, vp, a.ld, kb * 64, S, wave, lane);
-        if (threadIdx.x < 64) {
+        st_k.issue(base, kp, a.ld, kb * 64, S, wave);
+        st_v.issue(base + TB, vp, a.ld, kb * 64, S, wave);
+        // the bias row is read by masked blocks only (padding, tail, or the causal diagonal of some wave of this tile)
+        if (threadIdx.x < 64 && (a.kmask != nullptr || kb * 64 + 64 > S || (CAUSAL && kb * 64 + 63 > qb * 128))) {
             const int key = kb * 64 + threadIdx.x;
             const bool ok = key < S && (a.kmask == nullptr || a.kmask[rowbase + key] != 0);
             kbias[buf * 64 + threadIdx.x] = ok ? 0.f : -INFINITY;
@@ -229,29 +290,40 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 
     // One KV block (64 keys).  MASKED = false is the fast path for blocks that need no causal / padding / tail mask:
     // no compares, no bias loads, and exp2(fma(s, c, -m)) instead of scale + bias + subtract.
-    auto block = [&](auto MASKC, int kb, int buf) {
-        constexpr bool MASKED = decltype(MASKC)::value;
+    auto block = [&](const bool masked, int kb, int buf) {
         const MMU_LDS char* kt = (const MMU_LDS char*)smem + buf * 2 * TB;
         const MMU_LDS char* vt = kt + TB;
         const MMU_LDS float* kbs = (const MMU_LDS float*)(smem + 4 * TB) + buf * 64;
         f32x16 s[2];
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        {
+            // K fragments in batches of 4, software-pipelined: batch i+1 is requested before the MFMAs of batch i issue,
+            // so its LDS latency hides behind 4 MFMAs instead of stalling the chain (load -> wait -> MFMA per batch).
+            constexpr int NB = 2 * NKS / 4;  // batches over (st, h4)
+            bf16x8 kf[2][4];
+            auto load_k = [&](int bi, bf16x8 (&dst)[4]) {
+                const int st = bi / (NKS / 4), h4 = (bi % (NKS / 4)) * 4;
 #pragma unroll
-        for (int st = 0; st < 2; ++st) {
+                for (int ks = 0; ks < 4; ++ks) dst[ks] = *(const MMU_LDS bf16x8*)(kt + st * 32 * (D * 2) + fo_k.row[h4 + ks]);
+            };
+            load_k(0, kf[0]);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[st][r] = 0.f;
-#pragma unroll
-            for (int h4 = 0; h4 < NKS; h4 += 4) {  // fragment batches of 4: in flight before the first MFMA waits
-                bf16x8 kf[4];
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) kf[ks] = *(const MMU_LDS bf16x8*)(kt + st * 32 * (D * 2) + fo_k.row[h4 + ks]);
+            for (int bi = 0; bi < NB; ++bi) {
+                if (bi + 1 < NB) load_k(bi + 1, kf[(bi + 1) & 1]);
                 __builtin_amdgcn_sched_barrier(0);
+                const int st = bi / (NKS / 4), h4 = (bi % (NKS / 4)) * 4;
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
-                    s[st] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[h4 + ks], s[st], 0, 0, 0);
+                for (int ks = 0; ks < 4; ++ks)  // the chain starts from the inline constant 0
+                    s[st] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[bi & 1][ks], qf[h4 + ks],
+                                                                    (h4 + ks == 0) ? zero16 : s[st], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
+        // Only the softmax statistics differ between the masked and the mask-free block; the O rescale and the P V
+        // product below are shared code, so the 64 O accumulators stay in one set of registers (two instantiations of
+        // the whole block made the compiler copy all 64 at the merge: 64 v_mov per block).
         float mx = -INFINITY;
-        if (MASKED) {
+        if (masked) {
             const bool diag = CAUSAL && (kb * 64 + 63 > q0);
 #pragma unroll
             for (int st = 0; st < 2; ++st)
@@ -279,14 +351,25 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
         const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
         const float alpha = fast_exp2(m - m_use);
         float rs = 0.f;
+        if (masked) {
 #pragma unroll
-        for (int st = 0; st < 2; ++st)
+            for (int st = 0; st < 2; ++st)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = MASKED ? fast_exp2(s[st][r] - m_use) : fast_exp2(__builtin_fmaf(s[st][r], c, -m_use));
-                s[st][r] = p;
-                rs += p;
-            }
+                for (int r = 0; r < 16; ++r) {
+                    const float p = fast_exp2(s[st][r] - m_use);
+                    s[st][r] = p;
+                    rs += p;
+                }
+        } else {
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = fast_exp2(__builtin_fmaf(s[st][r], c, -m_use));
+                    s[st][r] = p;
+                    rs += p;
+                }
+        }
         lsum = lsum * alpha + rs;
         m = m_new;
 #pragma unroll
@@ -294,24 +377,29 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
         // O^T[d][q] += V^T[d][key] P^T[key][q]
+        {
+            // V^T fragments: one (key half, 16-key step) combination = NDT fragments per batch, software-pipelined like
+            // the K fragments (the 2-fragment batches with a barrier in between cost one LDS round trip per 2 MFMAs).
+            bf16x8 vf[2][NDT];
+            auto load_v = [&](int ci, bf16x8 (&dst)[NDT]) {
+                const int st = ci >> 1, sk = ci & 1;
 #pragma unroll
-        for (int st = 0; st < 2; ++st)
+                for (int dt = 0; dt < NDT; ++dt)
+                    dst[dt] = tr_load(vt + (st * 32 + sk * 16) * (D * 2) + fo_v.tr1[dt],
+                                      vt + (st * 32 + sk * 16) * (D * 2) + fo_v.tr2[dt]);
+            };
+            load_v(0, vf[0]);
 #pragma unroll
-            for (int sk = 0; sk < 2; ++sk) {
-                const bf16x8 pf = pack8(s[st], sk);
+            for (int ci = 0; ci < 4; ++ci) {
+                if (ci + 1 < 4) load_v(ci + 1, vf[(ci + 1) & 1]);
+                const bf16x8 pf = pack8(s[ci >> 1], ci & 1);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int d2 = 0; d2 < NDT; d2 += 2) {  // batches of 2 fragments keep the register budget at 256
-                    bf16x8 vf[2];
-#pragma unroll
-                    for (int dt = 0; dt < 2; ++dt)
-                        vf[dt] = tr_load(vt + (st * 32 + sk * 16) * (D * 2) + fo_v.tr1[d2 + dt],
-                                         vt + (st * 32 + sk * 16) * (D * 2) + fo_v.tr2[d2 + dt]);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int dt = 0; dt < 2; ++dt)
-                        o[d2 + dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt], pf, o[d2 + dt], 0, 0, 0);
-                }
+                for (int dt = 0; dt < NDT; ++dt)
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[ci & 1][dt], pf, o[dt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
+        }
     };
     stage(0, 0);
     for (int kb = 0; kb < nblk; ++kb) {
@@ -323,7 +411,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
         if (active) {
             // wave-uniform: does any element of this block need a mask?
             const bool masked = (CAUSAL && (kb * 64 + 63 > q0)) || (kb * 64 + 64 > S) || (a.kmask != nullptr);
-            if (masked) block(std::true_type{}, kb, cur); else block(std::false_type{}, kb, cur);
+            block(masked, kb, cur);
         }
     }
     const float ltot = lsum + __shfl_xor(lsum, 32, 64);
@@ -385,7 +473,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int hl = lane >> 5;
-    const int qb = blockIdx.x, hh = blockIdx.y, b = blockIdx.z;
+    int qb, hh, b;
+    decode_wg((a.S + 127) / 128, a.H, a.B, true, qb, hh, b);
     const int S = a.S;
     const size_t rowbase = (size_t)b * S;
     const bf16* qp = a.q + rowbase * a.ld + hh * D;
@@ -528,7 +617,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int kw = wave & 3, qh = wave >> 2;
     const int hl = lane >> 5;
-    const int kvb = blockIdx.x, hh = blockIdx.y, b = blockIdx.z;
+    int kvb, hh, b;
+    decode_wg((a.S + 127) / 128, a.H, a.B, false, kvb, hh, b);
     const int S = a.S;
     const size_t rowbase = (size_t)b * S;
     const bf16* qp = a.q + rowbase * a.ld + hh * D;
@@ -728,7 +818,7 @@ int launch_fwd(const AttnArgs& a, hipStream_t s) {
         if (e) return e;
         cfg = true;
     }
-    hipLaunchKernelGGL((attn_fwd_kernel<D, CAUSAL>), dim3((a.S + 127) / 128, a.H, a.B), dim3(256), LDS, s, a);
+    hipLaunchKernelGGL((attn_fwd_kernel<D, CAUSAL>), dim3(((a.S + 127) / 128) * a.H * a.B), dim3(256), LDS, s, a);
     MMU_CHECK_LAUNCH();
     return 0;
 }
@@ -749,9 +839,9 @@ int launch_bwd(const AttnArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((attn_delta_kernel<D>), dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, a.o, a.ldo, a.dout,
                        a.lddo, const_cast<float*>(a.delta), a.B, a.S, a.H);
     MMU_CHECK_LAUNCH();
-    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<D, CAUSAL>), dim3((a.S + 127) / 128, a.H, a.B), dim3(512), LDS_KV, s, a);
+    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<D, CAUSAL>), dim3(((a.S + 127) / 128) * a.H * a.B), dim3(512), LDS_KV, s, a);
     MMU_CHECK_LAUNCH();
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<D, CAUSAL>), dim3((a.S + 127) / 128, a.H, a.B), dim3(256), LDS_DQ, s, a);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<D, CAUSAL>), dim3(((a.S + 127) / 128) * a.H * a.B), dim3(256), LDS_DQ, s, a);
     MMU_CHECK_LAUNCH();
     return 0;
 }
