@@ -45,7 +45,9 @@ def flops_per_sample(cfg, S, paired=True, lora=False):
     clip = cfg.vision_layers_used * (2 * T * (4 * dv * dv + 2 * dv * iv) + 2 * 2 * T * T * dv) + 2 * v.num_patches * v.patch_k * dv
     proj = 2 * v.num_patches * (dv * d + d * d)
     fwd = dec + clip + proj
-    fb = fwd + (1 if lora else 2) * (dec + proj)  # LoRA: dgrad only (adapter GEMMs are < 1 %)
+    # LoRA: dgrad only (adapter GEMMs are < 1 %), including the dgrad sweep through the adapted CLIP tower (BASELINE.md
+    # §2: 30.16 T per sequence); full fine-tuning: dgrad + wgrad of decoder and projector, CLIP frozen (no backward)
+    fb = fwd + ((dec + proj + clip) if lora else 2 * (dec + proj))
     return (2 if paired else 1) * fb
 
 

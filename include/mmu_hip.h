@@ -89,6 +89,15 @@ int mmu_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* r
 int mmu_layernorm_fwd(const void* x, const void* w, const void* b, void* y, int M, int d, float eps, void* stream);
 
 /* ---- CLIP embeddings (CLIPVisionEmbeddings: patch conv as im2col+GEMM, cls/pos add; K1,K2) ---- */
+/* Backward pieces of the CLIP tower, needed when its Linears carry LoRA adapters (peft targets every nn.Linear,
+ * mm/forget.py:126-137): LayerNorm input gradient (+ residual gradient), quick-GELU forward / backward on the saved
+ * pre-activation, and the head-dim padding copy [M][H][d_src] -> [M][H][d_dst] that lets head_dim-64 attention run
+ * through the head_dim-128 backward kernels (zero padding leaves Q K^T and every gradient unchanged). */
+int mmu_layernorm_bwd(const void* dy, const void* x, const void* w, const void* dres, void* dx, int M, int d, float eps,
+                      void* stream);
+int mmu_quick_gelu_fwd(const void* x, void* y, long long n, void* stream);
+int mmu_quick_gelu_bwd(const void* x, const void* dy, void* dx, long long n, void* stream);
+int mmu_head_pad(const void* src, int ld_src, int d_src, void* dst, int ld_dst, int d_dst, int M, int H, void* stream);
 int mmu_im2col_patch(const float* pix, void* out, int B, int C, int H, int P, int Kpad, void* stream);
 /* CLIP image rescale + normalise on the device (replaces the processor's numpy rescale/normalize reached from
  * mm/dataset.py:310-317 `processor(text=..., images=...)`): in_u8 [n_img][3][hw] uint8 (resized + centre-cropped on

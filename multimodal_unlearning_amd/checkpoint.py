@@ -69,7 +69,12 @@ def _peft_modules(cfg: LlavaConfig, base: str, style: str):
     """Our (possibly fused) module name -> the HF module paths peft would have wrapped, in fused order."""
     from .params import _hf_prefixes
 
-    _, pj, lm, head = _hf_prefixes(style)
+    vt, pj, lm, head = _hf_prefixes(style)
+    if base.startswith("vision.layers."):
+        _, _, i, key = base.split(".")
+        sub, names = {"qkv": ("self_attn.", ("q_proj", "k_proj", "v_proj")), "out": ("self_attn.", ("out_proj",)),
+                      "fc1": ("mlp.", ("fc1",)), "fc2": ("mlp.", ("fc2",))}[key]
+        return [f"{vt}encoder.layers.{i}.{sub}{n}" for n in names]
     if base.startswith("projector."):
         return [pj + base[len("projector."):]]
     if base == "lm_head":

@@ -373,6 +373,130 @@ __global__ void swiglu_bwd_kernel(const bf16* __restrict__ gu, const bf16* __res
     }
 }
 
+// LayerNorm backward, input gradient only (the CLIP tower's LayerNorm weights stay frozen; its Linears may carry LoRA
+// adapters: mm/forget.py:126-137 targets every nn.Linear).  One wave per row, statistics recomputed from x:
+//   xh = (x - mean) rstd, g = dy w, dx = rstd (g - mean(g) - xh mean(g xh)) (+ dres).
+template <int MAXCH>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x,
+                                                            const bf16* __restrict__ w, const bf16* __restrict__ dres,
+                                                            bf16* __restrict__ dx, int M, int d, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nch = d >> 3;
+    const size_t off = (size_t)row * d;
+    float v[MAXCH][8], g[MAXCH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXCH; ++c) {
+        const int ch = c * 64 + lane;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { v[c][j] = 0.f; g[c][j] = 0.f; }
+        if (ch < nch) {
+            const bf16x8 t = *reinterpret_cast<const bf16x8*>(x + off + ch * 8);
+            const bf16x8 gy = *reinterpret_cast<const bf16x8*>(dy + off + ch * 8);
+            const bf16x8 wv = *reinterpret_cast<const bf16x8*>(w + ch * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                v[c][j] = bf2f(t[j]);
+                g[c][j] = bf2f(gy[j]) * bf2f(wv[j]);
+                s += v[c][j];
+            }
+        }
+    }
+    const float mean = wave_sum(s) / (float)d;
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXCH; ++c) {
+        const int ch = c * 64 + lane;
+        if (ch < nch) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                v[c][j] -= mean;
+                ss += v[c][j] * v[c][j];
+            }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(ss) / (float)d + eps);
+    float sg = 0.f, sgx = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXCH; ++c) {
+        const int ch = c * 64 + lane;
+        if (ch < nch) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                v[c][j] *= rstd;  // xh
+                sg += g[c][j];
+                sgx += g[c][j] * v[c][j];
+            }
+        }
+    }
+    const float mg = wave_sum(sg) / (float)d, mgx = wave_sum(sgx) / (float)d;
+#pragma unroll
+    for (int c = 0; c < MAXCH; ++c) {
+        const int ch = c * 64 + lane;
+        if (ch < nch) {
+            bf16x8 o;
+            if (dres) {
+                const bf16x8 r = *reinterpret_cast<const bf16x8*>(dres + off + ch * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = f2bf(rstd * (g[c][j] - mg - v[c][j] * mgx) + bf2f(r[j]));
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = f2bf(rstd * (g[c][j] - mg - v[c][j] * mgx));
+            }
+            *reinterpret_cast<bf16x8*>(dx + off + ch * 8) = o;
+        }
+    }
+}
+
+// quick-GELU x * sigmoid(1.702 x) (CLIP MLP act) forward / backward on the bf16 pre-activation
+__global__ void quick_gelu_fwd_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, size_t n8) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + i * 8);
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float f = bf2f(v[j]);
+            o[j] = f2bf(f / (1.0f + __expf(-1.702f * f)));
+        }
+        *reinterpret_cast<bf16x8*>(y + i * 8) = o;
+    }
+}
+__global__ void quick_gelu_bwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy, bf16* __restrict__ dx,
+                                      size_t n8) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + i * 8);
+        const bf16x8 g = *reinterpret_cast<const bf16x8*>(dy + i * 8);
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float f = bf2f(v[j]);
+            const float sg = 1.0f / (1.0f + __expf(-1.702f * f));
+            o[j] = f2bf(bf2f(g[j]) * sg * (1.0f + 1.702f * f * (1.0f - sg)));
+        }
+        *reinterpret_cast<bf16x8*>(dx + i * 8) = o;
+    }
+}
+
+// Head-dim padding copies: dst [M][H][dd] <- src [M][H][ds] (row strides ld*, elements), zero-filling dd > ds or
+// dropping the tail when dd < ds.  Used to run head_dim-64 attention (CLIP) through the head_dim-128 backward kernels.
+__global__ void head_pad_kernel(const bf16* __restrict__ src, int lds_, int ds, bf16* __restrict__ dst, int ldd, int dd,
+                                int M, int H) {
+    const int cd = dd >> 3, cs = ds >> 3;
+    const size_t total = (size_t)M * H * cd;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cd);
+        const int h = (int)((i / cd) % H);
+        const size_t m = i / ((size_t)cd * H);
+        bf16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = f2bf(0.f);
+        if (c < cs) v = *reinterpret_cast<const bf16x8*>(src + m * lds_ + h * ds + c * 8);
+        *reinterpret_cast<bf16x8*>(dst + m * ldd + h * dd + c * 8) = v;
+    }
+}
+
 // GELU (erf) forward / backward (LlavaMultiModalProjector act)
 __global__ void gelu_fwd_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, size_t n8) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
@@ -694,6 +818,44 @@ extern "C" int mmu_layernorm_fwd(const void* x, const void* w, const void* b, vo
                        (const bf16*)b, (bf16*)y, M, d, eps)
     MMU_MAXCH_DISPATCH(d, CALL);
 #undef CALL
+    MMU_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mmu_layernorm_bwd(const void* dy, const void* x, const void* w, const void* dres, void* dx, int M, int d,
+                                 float eps, void* stream) {
+    if (M <= 0 || (d & 7)) return -1;
+    hipStream_t s = (hipStream_t)stream;
+#define CALL(N)                                                                                                 \
+    hipLaunchKernelGGL(layernorm_bwd_kernel<N>, dim3((M + 3) / 4), dim3(256), 0, s, (const bf16*)dy, (const bf16*)x, \
+                       (const bf16*)w, (const bf16*)dres, (bf16*)dx, M, d, eps)
+    if (d <= 1024) { CALL(2); } else if (d <= 2048) { CALL(4); } else { return -1; }
+#undef CALL
+    MMU_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mmu_quick_gelu_fwd(const void* x, void* y, long long n, void* stream) {
+    if (n <= 0 || (n & 7)) return -1;
+    hipLaunchKernelGGL(quick_gelu_fwd_kernel, dim3(grid_for((size_t)n / 8, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16*)x, (bf16*)y, (size_t)n / 8);
+    MMU_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int mmu_quick_gelu_bwd(const void* x, const void* dy, void* dx, long long n, void* stream) {
+    if (n <= 0 || (n & 7)) return -1;
+    hipLaunchKernelGGL(quick_gelu_bwd_kernel, dim3(grid_for((size_t)n / 8, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16*)x, (const bf16*)dy, (bf16*)dx, (size_t)n / 8);
+    MMU_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int mmu_head_pad(const void* src, int ld_src, int d_src, void* dst, int ld_dst, int d_dst, int M, int H,
+                            void* stream) {
+    if (M <= 0 || H <= 0 || (d_src & 7) || (d_dst & 7) || (ld_src & 7) || (ld_dst & 7)) return -1;
+    if (((uintptr_t)src | (uintptr_t)dst) & 15) return -1;
+    const size_t work = (size_t)M * H * (d_dst >> 3);
+    hipLaunchKernelGGL(head_pad_kernel, dim3(grid_for(work, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)src,
+                       ld_src, d_src, (bf16*)dst, ld_dst, d_dst, M, H);
     MMU_CHECK_LAUNCH();
     return 0;
 }

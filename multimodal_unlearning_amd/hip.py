@@ -40,6 +40,10 @@ SIGNATURES = {
     "mmu_rmsnorm_bwd_nparts": [_i],
     "mmu_rmsnorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "mmu_layernorm_fwd": [_vp, _vp, _vp, _vp, _i, _i, _f, _vp],
+    "mmu_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
+    "mmu_quick_gelu_fwd": [_vp, _vp, _ll, _vp],
+    "mmu_quick_gelu_bwd": [_vp, _vp, _vp, _ll, _vp],
+    "mmu_head_pad": [_vp, _i, _i, _vp, _i, _i, _i, _i, _vp],
     "mmu_im2col_patch": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
     "mmu_clip_normalize_u8": [_vp, _vp, _ll, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _vp],
     "mmu_clip_embed": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
@@ -330,6 +334,33 @@ def gelu_bwd(x, dy, dx):
     _bf16c(x, dy, dx)
     _check(load().mmu_gelu_bwd(_p(x), _p(dy), _p(dx), x.numel(), _stream()), "mmu_gelu_bwd")
     return dx
+
+
+def layernorm_bwd(dy, x, w, dres, dx, eps):
+    _bf16c(dy, x, w, dres, dx)
+    M, d = x.shape
+    _check(load().mmu_layernorm_bwd(_p(dy), _p(x), _p(w), _p(dres), _p(dx), M, d, float(eps), _stream()), "mmu_layernorm_bwd")
+    return dx
+
+
+def quick_gelu_fwd(x, y):
+    _bf16c(x, y)
+    _check(load().mmu_quick_gelu_fwd(_p(x), _p(y), x.numel(), _stream()), "mmu_quick_gelu_fwd")
+    return y
+
+
+def quick_gelu_bwd(x, dy, dx):
+    _bf16c(x, dy, dx)
+    _check(load().mmu_quick_gelu_bwd(_p(x), _p(dy), _p(dx), x.numel(), _stream()), "mmu_quick_gelu_bwd")
+    return dx
+
+
+def head_pad(src, d_src, dst, d_dst, H):
+    """dst [M, H*d_dst] <- src [M, H*d_src] per head, zero-padding (d_dst > d_src) or dropping the tail."""
+    assert src.dtype == torch.bfloat16 and dst.dtype == torch.bfloat16 and src.stride(1) == 1 and dst.stride(1) == 1
+    M = src.shape[0]
+    _check(load().mmu_head_pad(_p(src), src.stride(0), d_src, _p(dst), dst.stride(0), d_dst, M, H, _stream()), "mmu_head_pad")
+    return dst
 
 
 def add(a, b, out):

@@ -39,11 +39,13 @@ BF = torch.bfloat16
 class LoraSpec:
     """peft LoraConfig subset used by the reference (mm/forget.py:126-137; config/mm/forget.yaml:3-6): rank r,
     alpha, dropout 0, bias "none".  Targets: decoder q|k|v, o, gate|up, down, lm_head (utils.py:10-19 only strips
-    the top-level name "lm_head", so under transformers 4.45.1 LLaVA's `language_model.lm_head` IS adapted) and the
-    two projector Linears.  The CLIP tower's Linears are NOT adapted here (that needs the CLIP backward; listed as
-    next in DESIGN.md) — `targets` makes the set explicit, as SURVEY.md §4 asks."""
+    the top-level name "lm_head", so under transformers 4.45.1 LLaVA's `language_model.lm_head` IS adapted), the two
+    projector Linears and — target "vision" — the q|k|v, out, fc1, fc2 Linears of the CLIP layers that feed the
+    projector (peft wraps every nn.Linear of the model, frozen tower included; the patch conv is not a Linear).
+    `targets` makes the set explicit, as SURVEY.md §4 asks."""
 
-    def __init__(self, r: int = 8, alpha: float = 32.0, targets=("qkv", "o", "gate_up", "down", "lm_head", "projector")):
+    def __init__(self, r: int = 8, alpha: float = 32.0,
+                 targets=("qkv", "o", "gate_up", "down", "lm_head", "projector", "vision")):
         self.r, self.alpha, self.targets = int(r), float(alpha), tuple(targets)
         self.scaling = self.alpha / self.r
 
@@ -238,6 +240,10 @@ class LlavaHIP(nn.Module):
     def _lora_targets(self, spec: LoraSpec):
         t = self.cfg.text
         out = []  # (weight name, k fused sub-modules)
+        if "vision" in spec.targets:
+            for i in range(self.cfg.vision_layers_used):
+                p = f"vision.layers.{i}."
+                out += [(p + "qkv.weight", 3), (p + "out.weight", 1), (p + "fc1.weight", 1), (p + "fc2.weight", 1)]
         if "projector" in spec.targets:
             out += [("projector.linear_1.weight", 1), ("projector.linear_2.weight", 1)]
         for i in range(t.num_layers):
@@ -572,8 +578,9 @@ class LlavaHIP(nn.Module):
         return logits
 
     # CLIP tower + projector -> image features [n_img*np, dt]; returns tensors needed by projector backward
-    def _vision_forward(self, pix):
+    def _vision_forward(self, pix, save: bool = False):
         cfg, v, w = self.cfg, self.cfg.vision, self.w
+        vlora = "vision.layers.0.qkv.weight" in self.lora
         dev = self.device
         n = pix.shape[0]
         npatch, T, dv = v.num_patches, v.num_patches + 1, v.hidden_size
@@ -590,7 +597,33 @@ class LlavaHIP(nn.Module):
         a = torch.empty_like(h)
         z = torch.empty(n * T, v.intermediate_size, device=dev, dtype=BF)
         scale = v.head_dim ** -0.5
-        for i in range(cfg.vision_layers_used):
+        clip_saved = [] if (vlora and save) else None
+        for i in range(cfg.vision_layers_used if vlora else 0):
+            # adapted tower: every Linear goes through _lin_fwd (fused low-rank term); the tensors the backward sweep
+            # needs are kept (35 MB each at 30 images: a few GB over 23 layers)
+            p = f"vision.layers.{i}."
+            y1 = torch.empty_like(h)
+            hip.layernorm_fwd(h, w[p + "ln1.weight"], w[p + "ln1.bias"], y1, v.layer_norm_eps)
+            qkv = torch.empty(n * T, 3 * dv, device=dev, dtype=BF)
+            self._lin_fwd(p + "qkv.weight", y1, qkv, bias=w[p + "qkv.bias"])
+            a = torch.empty_like(h)
+            lse = torch.empty(n, v.num_heads, T, device=dev, dtype=torch.float32) if save else None
+            hip.attn_fwd(qkv[:, :dv], qkv[:, dv:2 * dv], qkv[:, 2 * dv:], a, lse, None, n, T, v.num_heads,
+                         v.head_dim, scale, False)
+            h2 = torch.empty_like(h)
+            self._lin_fwd(p + "out.weight", a, h2, bias=w[p + "out.bias"], resid=h)
+            y2 = torch.empty_like(h)
+            hip.layernorm_fwd(h2, w[p + "ln2.weight"], w[p + "ln2.bias"], y2, v.layer_norm_eps)
+            z = torch.empty(n * T, v.intermediate_size, device=dev, dtype=BF)
+            self._lin_fwd(p + "fc1.weight", y2, z, bias=w[p + "fc1.bias"])
+            za = torch.empty_like(z)
+            hip.quick_gelu_fwd(z, za)
+            hn = torch.empty_like(h)
+            self._lin_fwd(p + "fc2.weight", za, hn, bias=w[p + "fc2.bias"], resid=h2)
+            if clip_saved is not None:
+                clip_saved.append((h, y1, qkv, a, lse, h2, y2, z, za))
+            h = hn
+        for i in range(0 if vlora else cfg.vision_layers_used):
             p = f"vision.layers.{i}."
             hip.layernorm_fwd(h, w[p + "ln1.weight"], w[p + "ln1.bias"], y, v.layer_norm_eps)
             hip.gemm(hip.NT, y, w[p + "qkv.weight"], qkv, bias=w[p + "qkv.bias"])
@@ -610,7 +643,48 @@ class LlavaHIP(nn.Module):
         hip.gelu_fwd(p1, p1a)
         img = torch.empty_like(p1)
         self._lin_fwd("projector.linear_2.weight", p1a, img, bias=w["projector.linear_2.bias"])
-        return img, (feats, p1, p1a)
+        return img, (feats, p1, p1a, clip_saved, n)
+
+    def _vision_backward(self, clip_saved, dfeats, n):
+        """Reverse sweep through the adapted CLIP layers: only the LoRA adapters of the tower receive gradients (its
+        base weights, LayerNorms and embeddings are frozen), so the chain carries dX only and stops at layer 0.
+        Attention (16 heads x 64) runs through the head_dim-128 backward kernels on zero-padded copies."""
+        v, w = self.cfg.vision, self.w
+        dev = self.device
+        T, dv, H, D = v.num_patches + 1, v.hidden_size, v.num_heads, v.head_dim
+        M = n * T
+        dh = torch.zeros(M, dv, device=dev, dtype=BF)
+        dh.view(n, T, dv)[:, 1:].copy_(dfeats.view(n, T - 1, dv))  # the CLS row feeds nothing downstream
+        scale = D ** -0.5
+        pad = lambda src: hip.head_pad(src, D, torch.empty(M, H * 128, device=dev, dtype=BF), 128, H)
+        delta = torch.empty(n, H, T, device=dev, dtype=torch.float32)
+        for i in reversed(range(len(clip_saved))):
+            p = f"vision.layers.{i}."
+            h, y1, qkv, a, lse, h2, y2, z, za = clip_saved[i]
+            clip_saved[i] = None
+            dza = torch.empty_like(za)
+            self._lin_bwd(p + "fc2.weight", dh, za, dza)
+            dz = torch.empty_like(z)
+            hip.quick_gelu_bwd(z, dza, dz)
+            dy2 = torch.empty_like(h)
+            self._lin_bwd(p + "fc1.weight", dz, y2, dy2)
+            dh2 = torch.empty_like(h)
+            hip.layernorm_bwd(dy2, h2, w[p + "ln2.weight"], dh, dh2, v.layer_norm_eps)
+            da = torch.empty_like(h)
+            self._lin_bwd(p + "out.weight", dh2, a, da)
+            qp, kp, vp = pad(qkv[:, :dv]), pad(qkv[:, dv:2 * dv]), pad(qkv[:, 2 * dv:])
+            op, dop = pad(a), pad(da)
+            dqp = torch.empty(M, 3 * H * 128, device=dev, dtype=BF)
+            hip.attn_bwd(qp, kp, vp, op, lse, None, dop, delta, dqp[:, :H * 128], dqp[:, H * 128:2 * H * 128],
+                         dqp[:, 2 * H * 128:], n, T, H, 128, scale, False)
+            dqkv = torch.empty(M, 3 * dv, device=dev, dtype=BF)
+            for j in range(3):
+                hip.head_pad(dqp[:, j * H * 128:(j + 1) * H * 128], 128, dqkv[:, j * dv:(j + 1) * dv], D, H)
+            dy1 = torch.empty_like(h)
+            self._lin_bwd(p + "qkv.weight", dqkv, y1, dy1)
+            dhn = torch.empty_like(h)
+            hip.layernorm_bwd(dy1, h, w[p + "ln1.weight"], dh2, dhn, v.layer_norm_eps)
+            dh = dhn
 
     def hidden_states(self, layer: int, input_ids=None, attention_mask=None, pixel_values=None, position_ids=None,
                       **_unused):
@@ -646,7 +720,7 @@ class LlavaHIP(nn.Module):
         img = None
         slot = None
         if pix is not None:
-            img, vis_saved = self._vision_forward(pix)
+            img, vis_saved = self._vision_forward(pix, save)
             slot = torch.empty(M, device=dev, dtype=torch.int32)
             cnt = torch.empty(1, device=dev, dtype=torch.int32)
             hip.image_slots(ids.view(-1), cfg.image_token_index, slot, cnt)
@@ -801,8 +875,9 @@ class LlavaHIP(nn.Module):
         # embeddings / projector
         slot = saved["slot"]
         dimg = None
+        clip_saved = None
         if "vis" in saved:
-            feats, p1, p1a = saved["vis"]
+            feats, p1, p1a, clip_saved, n_img = saved["vis"]
             dimg = torch.zeros(p1.shape[0], dt, device=dev, dtype=BF)
         if self._embed_scratch is None:
             self._embed_scratch = torch.zeros(V, dt, device=dev, dtype=torch.float32)
@@ -810,7 +885,9 @@ class LlavaHIP(nn.Module):
         hip.embed_bwd(saved["ids"].view(-1), slot, dh, dimg, self._embed_scratch, self._embed_flag,
                       g.get("text.embed_tokens.weight"), V)
         full = not self.lora
-        if dimg is not None and (full or "projector.linear_2.weight" in self.lora or "projector.linear_1.weight" in self.lora):
+        vlora = dimg is not None and clip_saved is not None
+        if dimg is not None and (full or vlora or "projector.linear_2.weight" in self.lora
+                                 or "projector.linear_1.weight" in self.lora):
             n = dimg.shape[0]
             cpart = torch.empty(hip.colsum_nparts(n) * dt, device=dev, dtype=torch.float32)
             dp1a = torch.empty_like(p1)
@@ -819,9 +896,12 @@ class LlavaHIP(nn.Module):
                 hip.colsum(dimg, cpart, g["projector.linear_2.bias"], True)
             dp1 = torch.empty_like(p1)
             hip.gelu_bwd(p1, dp1a, dp1)
-            self._lin_bwd("projector.linear_1.weight", dp1, feats, None)
+            dfeats = torch.empty_like(feats) if vlora else None
+            self._lin_bwd("projector.linear_1.weight", dp1, feats, dfeats)
             if full:
                 hip.colsum(dp1, cpart, g["projector.linear_1.bias"], True)
+            if vlora:
+                self._vision_backward(clip_saved, dfeats, n_img)
         if hook:  # everything laid out before decoder layer 0 (projector, token embedding)
             below = [self.range_of(n) for n in self._toff if n.startswith("projector.") or n.startswith("text.embed_tokens")]
             if below:

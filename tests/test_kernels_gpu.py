@@ -695,3 +695,39 @@ def test_gemm256_split_tail_matches(dev, layout, shape):
     finally:
         hip.gemm_set_tail_split(1)
         hip.gemm_set_tile(0)
+
+
+def test_clip_backward_pieces(dev):
+    """LayerNorm input gradient (+ residual), quick-GELU fwd/bwd and the head-dim padding copy vs torch autograd."""
+    M, d = 37, 1024
+    x = _randn((M, d), dev, 1.5, seed=31)
+    w = _randn((d,), dev, 1.0, seed=32)
+    dy = _randn((M, d), dev, 1.0, seed=33)
+    dres = _randn((M, d), dev, 1.0, seed=34)
+    xf = x.float().requires_grad_(True)
+    y = torch.nn.functional.layer_norm(xf, (d,), w.float(), None, 1e-5)
+    y.backward(dy.float())
+    dx = torch.empty_like(x)
+    hip.layernorm_bwd(dy, x, w, dres, dx, 1e-5)
+    assert _relerr(dx.float(), xf.grad + dres.float()) < 6e-3
+    hip.layernorm_bwd(dy, x, w, None, dx, 1e-5)
+    assert _relerr(dx.float(), xf.grad) < 6e-3
+    z = _randn((M, 4096), dev, 2.0, seed=35)
+    dz_up = _randn((M, 4096), dev, 1.0, seed=36)
+    zf = z.float().requires_grad_(True)
+    ya = zf * torch.sigmoid(1.702 * zf)
+    ya.backward(dz_up.float())
+    za, dz = torch.empty_like(z), torch.empty_like(z)
+    hip.quick_gelu_fwd(z, za)
+    hip.quick_gelu_bwd(z, dz_up, dz)
+    assert _relerr(za.float(), ya.detach()) < 4e-3 and _relerr(dz.float(), zf.grad) < 6e-3
+    H = 4
+    src = _randn((M, 3 * H * 64), dev, 1.0, seed=37)
+    padded = torch.empty(M, H * 128, device=dev, dtype=BF)
+    hip.head_pad(src[:, H * 64:2 * H * 64], 64, padded, 128, H)
+    ref = torch.zeros(M, H, 128, device=dev, dtype=BF)
+    ref[:, :, :64] = src[:, H * 64:2 * H * 64].reshape(M, H, 64)
+    assert torch.equal(padded.view(M, H, 128), ref)
+    back = torch.empty(M, H * 64, device=dev, dtype=BF)
+    hip.head_pad(padded, 128, back, 64, H)
+    assert torch.equal(back, src[:, H * 64:2 * H * 64])

@@ -359,6 +359,17 @@ def test_lora_grad_ascent_vs_oracle(dev):
             den += float(exp.pow(2).sum())
         assert float((gB * (1 - mask)).abs().max()) == 0.0  # off-block entries are not parameters
     assert (num / den) ** 0.5 < 3e-2, (num / den) ** 0.5
+    # the CLIP tower's adapters (peft wraps every nn.Linear): gradients arrive through the CLIP backward sweep
+    vis = [w for w in leaves if w.startswith("vision.")]
+    assert len(vis) == 4 * cfg.vision_layers_used
+    vn = vd = 0.0
+    for wname in vis:
+        A, Bm, mask = leaves[wname]
+        base = wname[: -len(".weight")]
+        for got, exp in ((model.g[base + ".lora_A"].float().cpu(), A.grad), (model.g[base + ".lora_B"].float().cpu(), Bm.grad * mask)):
+            vn += float((got - exp).pow(2).sum())
+            vd += float(exp.pow(2).sum())
+    assert vd > 0 and (vn / vd) ** 0.5 < 5e-2, (vn / max(vd, 1e-30)) ** 0.5
     st = model.lora_state()
     assert st["text.layers.0.qkv.lora_A"].shape == (24, cfg.text.hidden_size)
     assert st["text.layers.0.qkv.lora_B"].shape == (3 * cfg.text.hidden_size, 8)
