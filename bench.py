@@ -362,6 +362,7 @@ def main():
                        "paired_fusion": not args.no_fuse, "optimizer": "AdamW fp32 moments, clip 1.0", "lora_r": args.lora_r,
                        "keep_act_t": model.keep_act_t,
                        "decoder_layers": cfg.text.num_layers},
+            "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 1e9, 1),
             "step_tflops_per_gpu": round(value * fps / world / 1e12, 1),
             "step_frac_of_mfma_peak": round(value * fps / world / PEAK_BF16, 4),
             "roofline": {"bound": "mfma", "achieved": round(f / t / 1e12, 1), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",

@@ -471,6 +471,10 @@ class LlavaHIP(nn.Module):
     # -------------------------------------------------------------------------- transposed weight copies
     def _dgrad_weight_names(self):
         names = []
+        if "vision.layers.0.qkv.weight" in self.lora:  # adapted CLIP tower: its backward sweep needs dX = dY W too
+            for i in range(self.cfg.vision_layers_used):
+                p = f"vision.layers.{i}."
+                names += [p + "qkv.weight", p + "out.weight", p + "fc1.weight", p + "fc2.weight"]
         for i in range(self.cfg.text.num_layers):
             p = f"text.layers.{i}."
             names += [p + "qkv.weight", p + "o.weight", p + "gate_up.weight", p + "down.weight"]
