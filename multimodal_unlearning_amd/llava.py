@@ -208,6 +208,8 @@ class LlavaHIP(nn.Module):
         # keep act^T of every layer from forward to backward (+ layers*M*I*2 B, 23 GB at 7B / 30 sequences) instead of
         # recomputing it from gate|up in backward; the owner of the step turns it on when HBM allows (bench.py does)
         self.keep_act_t = False
+        self._fwd_U = None  # LoRA: x A^T of every adapted Linear of the forward in flight (-> saved["U"])
+        self._bwd_U = None
         if torch.device(device).type == "cuda":
             hip.ensure_gemm_workspace(torch.device(device))  # split-K tail partials (128 MiB, once per process)
         self.lora_splitk_min_m = 2048
@@ -369,6 +371,8 @@ class LlavaHIP(nn.Module):
             return hip.gemm(hip.NT, x, self.w[wname], out, bias=bias, resid=resid)
         U = torch.empty(x.shape[0], ad.kl, device=x.device, dtype=BF)
         hip.gemm(hip.NT, x, ad.A32s, U)  # s * x A^T
+        if self._fwd_U is not None:
+            self._fwd_U[wname] = U  # [M,32]: kept for the adapter wgrad dB = s dy^T (x A^T) instead of re-reading x
         return hip.gemm(hip.NT, x, self.w[wname], out, bias=bias, resid=resid, lora_u=U, lora_b=ad.BL)
 
     def _qkv_fwd(self, wname, x, qkv, pos, H, D, dt):
@@ -379,6 +383,8 @@ class LlavaHIP(nn.Module):
         if ad is not None:
             U = torch.empty(x.shape[0], ad.kl, device=x.device, dtype=BF)
             hip.gemm(hip.NT, x, ad.A32s, U)
+            if self._fwd_U is not None:
+                self._fwd_U[wname] = U
         if D == 128 and self.fuse_rope and hip.gemm_rope(x, self.w[wname], qkv, pos, self._cos, self._sin, 2 * dt, lora_u=U,
                                       lora_b=None if ad is None else ad.BL):
             return
@@ -409,8 +415,10 @@ class LlavaHIP(nn.Module):
                 hip.gemm(hip.NN, dy, self.w[wname], dx, lora_u=Vs, lora_b=ad.A32T)
         base = wname[: -len(".weight")]
         gA, gB = self.g[base + ".lora_A"], self.g[base + ".lora_B"]
-        U = torch.empty(M, ad.kl, device=dy.device, dtype=BF)
-        hip.gemm(hip.NT, x, ad.A32s, U)
+        U = self._bwd_U.pop(wname, None) if self._bwd_U is not None else None
+        if U is None:
+            U = torch.empty(M, ad.kl, device=dy.device, dtype=BF)
+            hip.gemm(hip.NT, x, ad.A32s, U)
         if M >= self.lora_splitk_min_m:
             # skinny outputs reduced over thousands of tokens: split-K over the tokens with fp32 accumulation
             scr = self._lora_scratch(max(gA.numel(), gB.numel()))
@@ -721,6 +729,7 @@ class LlavaHIP(nn.Module):
         dt, I, H, D = t.hidden_size, t.intermediate_size, t.num_heads, t.head_dim
         assert S <= t.max_position
         saved = {"B": B, "S": S, "ids": ids, "kmask": kmask, "pos": pos, "layers": [], "stop_layer": stop_layer}
+        self._fwd_U = saved.setdefault("U", {}) if (save and self.lora) else None
         img = None
         slot = None
         if pix is not None:
@@ -759,12 +768,15 @@ class LlavaHIP(nn.Module):
                 hip.swiglu_fwd(gu, act)
             hn = torch.empty(M, dt, device=dev, dtype=BF)
             self._lin_fwd(p + "down.weight", act, hn, resid=h2)
+            if save and actT is None and self.keep_act_t and self.lora:
+                actT = act  # LoRA sweep: the row-major act is the down-proj adapter's wgrad operand (no transposed path)
             if save:
                 saved["layers"].append((h, rstd1, qkv, a, lse, h2, rstd2, gu, actT))
             h = hn
             if self.capture_layer is not None and i == self.capture_layer:
                 self._last_capture = h.view(B, S, dt)
             if stop_layer is not None and i == stop_layer:
+                self._fwd_U = None
                 return h.view(B, S, dt), saved
         rstdf = torch.empty(M, device=dev, dtype=torch.float32)
         hip.rmsnorm_fwd(h, w["text.norm.weight"], y, rstdf, t.rms_norm_eps)
@@ -772,6 +784,7 @@ class LlavaHIP(nn.Module):
         self._lin_fwd("lm_head.weight", y, logits)
         if save:
             saved["final"] = (h, rstdf)
+        self._fwd_U = None
         return logits.view(B, S, t.vocab_size), saved
 
     # ---------------------------------------------------------------------------------------- backward
@@ -780,6 +793,7 @@ class LlavaHIP(nn.Module):
         dev = self.device
         self.ensure_grad()
         g = self.g
+        self._bwd_U = saved.get("U")
         B, S = saved["B"], saved["S"]
         M = B * S
         dt, I, H, D, V = t.hidden_size, t.intermediate_size, t.num_heads, t.head_dim, t.vocab_size
@@ -841,8 +855,10 @@ class LlavaHIP(nn.Module):
                 self._dgrad(dgu, p + "gate_up.weight", dy)
                 del dguT
             else:
-                act = torch.empty(M, I, device=dev, dtype=BF)
-                hip.swiglu_fwd(gu, act)
+                act = actT
+                if act is None:
+                    act = torch.empty(M, I, device=dev, dtype=BF)
+                    hip.swiglu_fwd(gu, act)
                 self._lin_bwd(p + "down.weight", dh, act, dact)
                 hip.swiglu_bwd(gu, dact, dgu)
                 del act, dact, gu
