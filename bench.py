@@ -204,7 +204,7 @@ def hbm_kernels(hip, cfg, n_seq, S, dev, reps=5):
     NP = 1 << 28
     p, gr = rnd(NP), rnd(NP)
     m1, v1 = torch.zeros(NP, device=dev), torch.zeros(NP, device=dev)
-    ss = torch.ones(1, device=dev, dtype=torch.float32)
+    ss = torch.ones(hip.SUMSQ_FLOATS, device=dev, dtype=torch.float32)
     cases = [
         ("rmsnorm_fwd", 2 * M * d * 2 + M * 4, lambda: hip.rmsnorm_fwd(x, w, y, rstd, 1e-5)),
         ("rmsnorm_bwd (+residual grad, dgamma partials)", 4 * M * d * 2, lambda: hip.rmsnorm_bwd(dy, x, w, rstd, dres, y, dwp, dw, True)),

@@ -164,7 +164,10 @@ int mmu_l1l0_fwd(const void* p, const void* t, long long n, double* out2, void* 
 int mmu_l1_bwd(const void* p, const void* t, long long n, void* g, float lambda1, const float* gout, void* stream);
 
 /* ---- Optimiser step after compute_loss (HF loop: clip_grad_norm_ -> AdamW -> zero_grad; mm/forget.py:139-168) ---- */
+/* out_sumsq[0] <- sum g^2, deterministic (fixed summation order: every DP rank must derive the same clip factor from
+ * the same all-reduced gradient); out_sumsq needs 1 + mmu_sumsq_scratch_floats() floats (partials after slot 0). */
 int mmu_sumsq_bf16(const void* g, long long n, float* out_sumsq, void* stream);
+int mmu_sumsq_scratch_floats(void);
 int mmu_adamw_bf16(void* p, void* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
                    float weight_decay, int step, const float* sumsq, float max_norm, float grad_scale, int zero_grad,
                    void* stream);

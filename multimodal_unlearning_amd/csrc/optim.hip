@@ -9,7 +9,11 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void sumsq_kernel(const bf16* __restrict__ g, size_t n8, float* __restrict__ out) {
+// Sum of squares in two passes with a FIXED summation order (per-block partials, then one block folds them): every
+// data-parallel rank derives the clip factor from the same all-reduced gradient and must get the same bits, or the
+// replicas drift apart (a float atomicAdd over the blocks differs in the last ulp from run to run).
+constexpr int SUMSQ_MAX_PARTS = 2048;
+__global__ __launch_bounds__(256) void sumsq_kernel(const bf16* __restrict__ g, size_t n8, float* __restrict__ part) {
     __shared__ float scratch[4];
     float s = 0.f;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
@@ -21,7 +25,14 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const bf16* __restrict__ g, 
         }
     }
     s = block_sum<4>(s, scratch);
-    if (threadIdx.x == 0) atomicAdd(out, s);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void sumsq_fold_kernel(const float* __restrict__ part, int nparts, float* __restrict__ out) {
+    __shared__ float scratch[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += 256) s += part[i];
+    s = block_sum<4>(s, scratch);
+    if (threadIdx.x == 0) out[0] = s;
 }
 
 // L1 / L0 "norm" of d = bf16(p - t) (t = null: d = p): out[0] += sum |d|, out[1] += #(d != 0)  (fp64 accumulators).
@@ -134,16 +145,20 @@ __global__ void scale_kernel(bf16* __restrict__ x, size_t n8, float s) {
 
 }  // namespace
 
-// out_sumsq += sum(g^2). n % 8 == 0. The caller zeroes out_sumsq (hipMemsetAsync) before the first bucket.
+// out_sumsq[0] <- sum(g^2), n % 8 == 0; deterministic (see sumsq_kernel).
 extern "C" int mmu_sumsq_bf16(const void* g, long long n, float* out_sumsq, void* stream) {
     if (n <= 0 || (n & 7)) return -1;
     const size_t n8 = (size_t)n / 8;
     size_t grid = (n8 + 255) / 256;
     if (grid > 2048) grid = 2048;
-    hipLaunchKernelGGL(sumsq_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)g, n8, out_sumsq);
+    // out_sumsq[0] <- sum g^2; out_sumsq[1 .. 1 + mmu_sumsq_scratch_floats()) is scratch for the per-block partials
+    hipLaunchKernelGGL(sumsq_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)g, n8, out_sumsq + 1);
+    MMU_CHECK_LAUNCH();
+    hipLaunchKernelGGL(sumsq_fold_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, out_sumsq + 1, (int)grid, out_sumsq);
     MMU_CHECK_LAUNCH();
     return 0;
 }
+extern "C" int mmu_sumsq_scratch_floats(void) { return SUMSQ_MAX_PARTS; }
 
 extern "C" int mmu_l1l0_fwd(const void* p, const void* t, long long n, double* out2, void* stream) {
     if (n <= 0 || (n & 7) || !out2) return -1;

@@ -96,7 +96,7 @@ class ForgetEngine:
         n = self.grad.numel()
         self.m = torch.zeros(n, device=dev, dtype=torch.float32)
         self.v = torch.zeros(n, device=dev, dtype=torch.float32)
-        self.sumsq = torch.zeros(1, device=dev, dtype=torch.float32)
+        self.sumsq = torch.zeros(hip.SUMSQ_FLOATS, device=dev, dtype=torch.float32)  # [0] = |g|^2, rest scratch
         self.opt_step = 0
         self.reducer = GradBucketReducer(self.grad, group, force=force_collectives)
         if transposed_weights:
@@ -117,7 +117,6 @@ class ForgetEngine:
         self.reducer.wait()
         self.opt_step += 1
         lr = linear_schedule(self.opt_step, self.cfg.lr, self.warmup_steps, self.total_steps)
-        self.sumsq.zero_()
         self.hip.sumsq(self.grad, self.sumsq)
         self.hip.adamw(model.train_flat.data, self.grad, self.m, self.v, lr, self.cfg.adam_beta1, self.cfg.adam_beta2,
                        self.cfg.adam_eps, self.cfg.weight_decay, self.opt_step, self.sumsq, self.cfg.max_grad_norm,

@@ -72,6 +72,7 @@ SIGNATURES = {
     "mmu_l1l0_fwd": [_vp, _vp, _ll, _vp, _vp],
     "mmu_l1_bwd": [_vp, _vp, _ll, _vp, _f, _vp, _vp],
     "mmu_sumsq_bf16": [_vp, _ll, _vp, _vp],
+    "mmu_sumsq_scratch_floats": [],
     "mmu_adamw_bf16": [_vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _f, _i, _vp, _f, _f, _i, _vp],
     "mmu_scale_bf16": [_vp, _ll, _f, _vp],
 }
@@ -488,8 +489,13 @@ def l1_bwd(p, t, g, lambda1, gout):
     _check(load().mmu_l1_bwd(_p(p), _p(t), p.numel(), _p(g), float(lambda1), _p(gout), _stream()), "mmu_l1_bwd")
 
 
+SUMSQ_FLOATS = 1 + 2048  # out[0] = result, the rest is scratch for the per-block partials
+
+
 def sumsq(g, out):
+    """out[0] <- sum g^2 (deterministic two-pass reduction); out: float32, >= SUMSQ_FLOATS elements."""
     _bf16c(g)
+    assert out.dtype == torch.float32 and out.numel() >= SUMSQ_FLOATS and out.is_contiguous()
     _check(load().mmu_sumsq_bf16(_p(g), g.numel(), _p(out), _stream()), "mmu_sumsq_bf16")
 
 

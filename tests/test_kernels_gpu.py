@@ -474,9 +474,12 @@ def test_adamw_and_gradnorm(dev):
     pf = p0.float().clone()  # fp32 shadow of the bf16-rounded trajectory is not kept: compare per step
     for step in range(1, 4):
         g = _randn((n,), dev, 3.0, 10 + step)
-        ss = torch.zeros(1, device=dev)
+        ss = torch.zeros(hip.SUMSQ_FLOATS, device=dev)
         hip.sumsq(g, ss)
-        assert abs(ss.item() - g.float().pow(2).sum().item()) < 1e-3 * ss.item()
+        assert abs(ss[0].item() - g.float().pow(2).sum().item()) < 1e-3 * ss[0].item()
+        ss2 = torch.full((hip.SUMSQ_FLOATS,), 7.0, device=dev)
+        hip.sumsq(g, ss2)
+        assert ss2[0].item() == ss[0].item()  # fixed summation order: bit-identical, whatever the buffer held
         # reference step from the CURRENT bf16 params (isolates one update)
         pr.data.copy_(p.float())
         pr.grad = g.float().clone()
