@@ -248,6 +248,9 @@ def main():
     ap.add_argument("--gemm-persist", type=int, default=None, help="A/B: 256^2 GEMM launch mode (0 workgroup per tile, 1 persistent)")
     ap.add_argument("--gemm-tail-split", type=int, default=None, help="A/B: split-K tail of the 256^2 GEMM (0 off, 1 heuristic = default)")
     ap.add_argument("--keep-act-t", type=int, default=None, help="keep act^T from forward to backward (default: on when it costs <= 24 GB)")
+    ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); gloo + --single-device "
+                    "rehearses the N > 1 launch path on a 1-GPU box")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--hbm-kernels", action="store_true",
                     help="also time the step's HBM-bound kernels standalone (bytes next to GB/s) after the timed region")
     ap.add_argument("--no-fuse", action="store_true")
@@ -267,7 +270,12 @@ def main():
         hip.gemm_set_tail_split(args.gemm_tail_split)
     if args.gemm_persist is not None:
         hip.gemm_set_persistent(args.gemm_persist)
-    rank, local, world = init_distributed()
+    if os.environ.get("MMU_DUMP_AFTER"):  # debugging aid for rehearsals: dump every thread's stack and exit
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["MMU_DUMP_AFTER"]), exit=True)
+    if args.single_device:
+        os.environ["LOCAL_RANK"] = "0"
+    rank, local, world = init_distributed(args.backend)
     assert world == args.gpus or world == 1 and args.gpus == 1, f"launched {world} ranks for --gpus {args.gpus}"
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback for the HIP path)"
     torch.cuda.set_device(local)

@@ -53,12 +53,18 @@ class GradBucketReducer:
         self.reduced_elems = 0
         # force=True runs the collectives even on a 1-rank group (exercises the RCCL path on a single GPU)
         self.enabled = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force)
+        self._gloo = self.enabled and dist.get_backend(group) == "gloo"
 
     def reduce_range(self, lo: int, hi: int):
         if not self.enabled:
             return
         while lo < hi:
             e = min(hi, lo + self.max_bucket)
+            # RCCL runs the buckets in stream order, any number may be in flight.  gloo (CPU plumbing mode, rehearsals)
+            # executes async works on a small thread pool: with >= 4 ranks and many works in flight the ranks' pools
+            # pick different buckets and wait for each other forever (seen with 4 ranks on one GPU) -> at most 2 there.
+            if self._gloo and len(self.works) >= 2:
+                self.works.pop(0).wait()
             self.works.append(dist.all_reduce(self.flat[lo:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
             self.reduced_elems += e - lo
             lo = e
