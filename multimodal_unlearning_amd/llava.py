@@ -922,8 +922,9 @@ class LlavaHIP(nn.Module):
                 hip.colsum(dp1, cpart, g["projector.linear_1.bias"], True)
             if vlora:
                 self._vision_backward(clip_saved, dfeats, n_img)
-        if hook:  # everything laid out before decoder layer 0 (projector, token embedding)
-            below = [self.range_of(n) for n in self._toff if n.startswith("projector.") or n.startswith("text.embed_tokens")]
+        if hook:  # everything else: projector, token embedding, the CLIP tower's adapters
+            below = [self.range_of(n) for n in self._toff
+                     if n.startswith("projector.") or n.startswith("text.embed_tokens") or n.startswith("vision.")]
             if below:
                 hook(min(a for a, _ in below), max(b for _, b in below))
 

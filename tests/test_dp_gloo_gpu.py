@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _build(dev):
+def _build(dev, lora=False):
     from multimodal_unlearning_amd.config import ForgetConfig, tiny_test_config
     from multimodal_unlearning_amd.engine import ForgetEngine
     from multimodal_unlearning_amd.llava import LlavaHIP
@@ -29,21 +29,27 @@ def _build(dev):
     from multimodal_unlearning_amd.trainer import MMTrainerForgetting
 
     cfg = tiny_test_config()
-    model = LlavaHIP(cfg, init_params(cfg, seed=0), device=dev)
+    if lora:
+        from multimodal_unlearning_amd.llava import LoraSpec
+
+        model = LlavaHIP(cfg, init_params(cfg, seed=0), device=dev, lora=LoraSpec(r=8, alpha=32.0))
+        model.init_lora_(seed=3, b_std=0.02)
+    else:
+        model = LlavaHIP(cfg, init_params(cfg, seed=0), device=dev)
     tr = MMTrainerForgetting(model=model, forget_loss="grad_diff_forget_ce_retain_ce", teacher_model=None, loss_beta=1.0,
                              l1_lambda=0.0, l0_lambda=0.0, l_norm_from="zero")
     eng = ForgetEngine(model, tr, ForgetConfig(lr=1e-3), total_steps=10, warmup_steps=1)
     return cfg, model, eng
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, lora):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from multimodal_unlearning_amd.synthetic import make_forget_batch
 
-        cfg, model, eng = _build("cuda:0")
+        cfg, model, eng = _build("cuda:0", lora)
         assert eng.reducer.enabled and eng.world == 2
         for step in range(2):
             mb = make_forget_batch(cfg, 2, 40, seed=50 + 10 * step + rank, n_question=6)
@@ -54,11 +60,12 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_two_ranks_match_gradient_accumulation():
+@pytest.mark.parametrize("lora", [False, True])
+def test_two_ranks_match_gradient_accumulation(lora):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q, lora)) for r in range(2)]
     for p in ps:
         p.start()
     res = {r: torch.from_numpy(a) for r, a in (q.get(timeout=300) for _ in ps)}
@@ -68,12 +75,12 @@ def test_two_ranks_match_gradient_accumulation():
     assert torch.equal(res[0], res[1])  # replicas stay identical
     from multimodal_unlearning_amd.synthetic import make_forget_batch
 
-    cfg, model, eng = _build("cuda:0")
+    cfg, model, eng = _build("cuda:0", lora)
     for step in range(2):
         eng.step([make_forget_batch(cfg, 2, 40, seed=50 + 10 * step + r, n_question=6) for r in range(2)])
     torch.cuda.synchronize()
     ref = model.train_flat.detach().float().cpu()
     err = (res[0] - ref).norm() / ref.norm()
-    moved = (ref - _build("cuda:0")[1].train_flat.detach().float().cpu()).norm() / ref.norm()
+    moved = (ref - _build("cuda:0", lora)[1].train_flat.detach().float().cpu()).norm() / ref.norm()
     # bf16 gradients: rank-sum then 1/2 vs accumulate-of-halves differ in rounding only
     assert moved > 1e-3 and err < 0.05 * moved, (float(err), float(moved))
