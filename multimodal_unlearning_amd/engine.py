@@ -51,6 +51,7 @@ class GradBucketReducer:
         self.max_bucket = max_bucket_elems
         self.works = []
         self.reduced_elems = 0
+        self.done = []  # [lo, hi) intervals already handed to a collective in this step
         # force=True runs the collectives even on a 1-rank group (exercises the RCCL path on a single GPU)
         self.enabled = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force)
         self._gloo = self.enabled and dist.get_backend(group) == "gloo"
@@ -58,6 +59,7 @@ class GradBucketReducer:
     def reduce_range(self, lo: int, hi: int):
         if not self.enabled:
             return
+        self.done.append((lo, hi))
         while lo < hi:
             e = min(hi, lo + self.max_bucket)
             # RCCL runs the buckets in stream order, any number may be in flight.  gloo (CPU plumbing mode, rehearsals)
@@ -69,7 +71,23 @@ class GradBucketReducer:
             self.reduced_elems += e - lo
             lo = e
 
+    def reduce_rest(self):
+        """All-reduce whatever no hook covered (a loss whose last sweep never ran — dead forwards keep the model's
+        live-sweep count above zero — or a model without hooks): the complement of the intervals seen so far."""
+        if not self.enabled:
+            return
+        pos, n, gaps = 0, self.flat.numel(), []
+        for lo, hi in sorted(self.done):
+            if lo > pos:
+                gaps.append((pos, lo))
+            pos = max(pos, hi)
+        if pos < n:
+            gaps.append((pos, n))
+        for lo, hi in gaps:
+            self.reduce_range(lo, hi)
+
     def wait(self):
+        self.done = []
         for w in self.works:
             w.wait()
         self.works = []
@@ -115,11 +133,13 @@ class ForgetEngine:
         for i, mb in enumerate(micro_batches):
             last = i == ga - 1
             model.grad_ready_hook = self.reducer.reduce_range if (last and self.reducer.enabled) else None
+            model.live_sweeps = 0
             loss = self.trainer.compute_loss(model, mb)
             (loss / ga).backward()
             d = loss.detach().float()
             total = d if total is None else total + d
         model.grad_ready_hook = None
+        self.reducer.reduce_rest()
         self.reducer.wait()
         self.opt_step += 1
         lr = linear_schedule(self.opt_step, self.cfg.lr, self.warmup_steps, self.total_steps)

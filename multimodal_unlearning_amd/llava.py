@@ -229,6 +229,13 @@ class LlavaHIP(nn.Module):
         # hook: called as fn(lo, hi) with the [lo,hi) element range of the flat gradient that is final for this
         # backward (used by the DP engine to start the RCCL all-reduce of a bucket while backward continues)
         self.grad_ready_hook: Optional[Callable[[int, int], None]] = None
+        # Autograd edges (forwards with a saved graph) whose backward sweep has not run yet.  A loss with several student
+        # forwards (kl, scrub, llmu, dpo, un-fused grad_diff ...) runs several sweeps in one loss.backward(): the
+        # gradient buckets may only be handed to grad_ready_hook by the LAST of them (an earlier sweep's all-reduce would
+        # be summed over the ranks again after the later sweeps added to it).  The owner of the step resets the counter
+        # per micro-batch (a forward whose output is never used, as in the reference's dpo branch, never sweeps; the
+        # engine then reduces what no hook covered).
+        self.live_sweeps = 0
         self.capture_layer: Optional[int] = None
         if self.lora:
             self.init_lora_(seed)
@@ -788,7 +795,7 @@ class LlavaHIP(nn.Module):
         return logits.view(B, S, t.vocab_size), saved
 
     # ---------------------------------------------------------------------------------------- backward
-    def _backward_impl(self, saved, dlogits):
+    def _backward_impl(self, saved, dlogits, fire_hooks: bool = True):
         cfg, t, w = self.cfg, self.cfg.text, self.w
         dev = self.device
         self.ensure_grad()
@@ -806,7 +813,7 @@ class LlavaHIP(nn.Module):
         npart = hip.rmsnorm_bwd_nparts(M)
         dw_part = torch.empty(npart * dt, device=dev, dtype=torch.float32)
         y = torch.empty(M, dt, device=dev, dtype=BF)
-        hook = self.grad_ready_hook
+        hook = self.grad_ready_hook if fire_hooks else None
 
         stop_layer = saved.get("stop_layer")
         dy = torch.empty(M, dt, device=dev, dtype=BF)
@@ -936,6 +943,7 @@ class _LlavaFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, train_flat, model: LlavaHIP, ids, kmask, pix, pos, stop_layer=None):
         logits, saved = model._forward_impl(ids, kmask, pix, pos, save=True, stop_layer=stop_layer)
+        model.live_sweeps += 1
         ctx.model = model
         ctx.saved = saved
         return logits
@@ -944,5 +952,6 @@ class _LlavaFn(torch.autograd.Function):
     def backward(ctx, dlogits):
         model, saved = ctx.model, ctx.saved
         ctx.saved = None
-        model._backward_impl(saved, dlogits)
+        model.live_sweeps = max(0, model.live_sweeps - 1)
+        model._backward_impl(saved, dlogits, fire_hooks=model.live_sweeps == 0)
         return None, None, None, None, None, None, None

@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _build(dev, lora=False):
+def _build(dev, lora=False, loss="grad_diff_forget_ce_retain_ce", loss_args=None):
     from multimodal_unlearning_amd.config import ForgetConfig, tiny_test_config
     from multimodal_unlearning_amd.engine import ForgetEngine
     from multimodal_unlearning_amd.llava import LlavaHIP
@@ -36,23 +36,28 @@ def _build(dev, lora=False):
         model.init_lora_(seed=3, b_std=0.02)
     else:
         model = LlavaHIP(cfg, init_params(cfg, seed=0), device=dev)
-    tr = MMTrainerForgetting(model=model, forget_loss="grad_diff_forget_ce_retain_ce", teacher_model=None, loss_beta=1.0,
-                             l1_lambda=0.0, l0_lambda=0.0, l_norm_from="zero")
+    teacher = None
+    if loss in ("kl", "dpo"):
+        from multimodal_unlearning_amd.synthetic import teacher_params_from
+
+        teacher = LlavaHIP(cfg, teacher_params_from(init_params(cfg, seed=0), seed=7), device=dev, trainable=False)
+    tr = MMTrainerForgetting(model=model, forget_loss=loss, teacher_model=teacher, loss_beta=1.0,
+                             l1_lambda=0.0, l0_lambda=0.0, l_norm_from="zero", loss_args=loss_args or {})
     eng = ForgetEngine(model, tr, ForgetConfig(lr=1e-3), total_steps=10, warmup_steps=1)
     return cfg, model, eng
 
 
-def _worker(rank, world, port, q, lora):
+def _worker(rank, world, port, q, lora, loss, loss_args):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from multimodal_unlearning_amd.synthetic import make_forget_batch
 
-        cfg, model, eng = _build("cuda:0", lora)
+        cfg, model, eng = _build("cuda:0", lora, loss, loss_args)
         assert eng.reducer.enabled and eng.world == 2
         for step in range(2):
-            mb = make_forget_batch(cfg, 2, 40, seed=50 + 10 * step + rank, n_question=6)
+            mb = make_forget_batch(cfg, 2, 40, seed=50 + 10 * step + rank, n_question=6, splits=SPLITS)
             eng.step([mb])
         torch.cuda.synchronize()
         q.put((rank, model.train_flat.detach().float().cpu().numpy()))  # numpy: no fd passing after exit
@@ -60,12 +65,21 @@ def _worker(rank, world, port, q, lora):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("lora", [False, True])
-def test_two_ranks_match_gradient_accumulation(lora):
+SPLITS = ("forget", "retain", "idk")
+
+
+@pytest.mark.parametrize("lora,loss,loss_args", [
+    (False, "grad_diff_forget_ce_retain_ce", None),                  # paired fusion: one backward sweep
+    (True, "grad_diff_forget_ce_retain_ce", None),                   # adapters incl. the CLIP tower's
+    (False, "grad_diff_forget_ce_retain_ce", {"fuse_pairs": False}),  # two sweeps in one loss.backward()
+    (False, "kl", None),                                             # two student sweeps + a frozen teacher
+    (False, "dpo", None),                                            # a forward that never sweeps (reference quirk)
+])
+def test_two_ranks_match_gradient_accumulation(lora, loss, loss_args):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    ps = [ctx.Process(target=_worker, args=(r, 2, port, q, lora)) for r in range(2)]
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q, lora, loss, loss_args)) for r in range(2)]
     for p in ps:
         p.start()
     res = {r: torch.from_numpy(a) for r, a in (q.get(timeout=300) for _ in ps)}
@@ -75,12 +89,12 @@ def test_two_ranks_match_gradient_accumulation(lora):
     assert torch.equal(res[0], res[1])  # replicas stay identical
     from multimodal_unlearning_amd.synthetic import make_forget_batch
 
-    cfg, model, eng = _build("cuda:0", lora)
+    cfg, model, eng = _build("cuda:0", lora, loss, loss_args)
     for step in range(2):
-        eng.step([make_forget_batch(cfg, 2, 40, seed=50 + 10 * step + r, n_question=6) for r in range(2)])
+        eng.step([make_forget_batch(cfg, 2, 40, seed=50 + 10 * step + r, n_question=6, splits=SPLITS) for r in range(2)])
     torch.cuda.synchronize()
     ref = model.train_flat.detach().float().cpu()
     err = (res[0] - ref).norm() / ref.norm()
-    moved = (ref - _build("cuda:0", lora)[1].train_flat.detach().float().cpu()).norm() / ref.norm()
+    moved = (ref - _build("cuda:0", lora, loss, loss_args)[1].train_flat.detach().float().cpu()).norm() / ref.norm()
     # bf16 gradients: rank-sum then 1/2 vs accumulate-of-halves differ in rounding only
     assert moved > 1e-3 and err < 0.05 * moved, (float(err), float(moved))
