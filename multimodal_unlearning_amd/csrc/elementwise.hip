@@ -652,29 +652,47 @@ __global__ void embed_flush_kernel(float* __restrict__ scratch, int* __restrict_
 
 
 // Tiled bf16 transpose: dst[c][r] = src[r][c]; 64x64 tiles through LDS, 16-B global accesses both ways.
+// A thread loads 8 columns of two ADJACENT source rows, packs the row pair of every column into one dword and writes
+// the transposed tile [64 columns][row pairs] with ds_write_b32; the read side is then one 16-B LDS read (8 source
+// rows of one column) per 16-B global store.  The tile is 64 columns x TR source rows: a taller tile makes the
+// output runs longer (TR * 2 bytes per output row and block; the large transposes are bound by the strided write).
+template <int TR>
 __global__ __launch_bounds__(256) void transpose_kernel(const bf16* __restrict__ src, bf16* __restrict__ dst, int R,
                                                         int C) {
-    __shared__ bf16 tile[64][72];  // +8 pad: 144-B rows keep 16-B alignment and spread banks
-    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
-    const int tr = threadIdx.x >> 3, tc = (threadIdx.x & 7) * 8;  // 32 rows x 8 chunks per pass
+    constexpr int NP = TR / 2;                                                  // row pairs per tile
+    __shared__ __attribute__((aligned(16))) unsigned int tileT[64][NP + 4];    // [source column][row pair]
+    const int r0 = blockIdx.y * TR, c0 = blockIdx.x * 64;
+    const int tc = (threadIdx.x & 7) * 8;
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const int r = r0 + tr + p * 32, c = c0 + tc;
-        bf16x8 v;
+    for (int g = 0; g < NP / 32; ++g) {
+        const int tp = (threadIdx.x >> 3) + g * 32;  // row pair
+        const int r = r0 + 2 * tp, c = c0 + tc;
+        bf16x8 a, b;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = f2bf(0.f);
-        if (r < R && c < C) v = *reinterpret_cast<const bf16x8*>(src + (size_t)r * C + c);
-        *reinterpret_cast<bf16x8*>(&tile[tr + p * 32][tc]) = v;
+        for (int j = 0; j < 8; ++j) { a[j] = f2bf(0.f); b[j] = f2bf(0.f); }
+        if (c < C) {
+            if (r < R) a = *reinterpret_cast<const bf16x8*>(src + (size_t)r * C + c);
+            if (r + 1 < R) b = *reinterpret_cast<const bf16x8*>(src + (size_t)(r + 1) * C + c);
+        }
+        const uint4 au = __builtin_bit_cast(uint4, a), bu = __builtin_bit_cast(uint4, b);
+        const unsigned int aw[4] = {au.x, au.y, au.z, au.w}, bw[4] = {bu.x, bu.y, bu.z, bu.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {  // dword k holds columns 2k (low half) and 2k+1 (high half)
+            tileT[tc + 2 * k][tp] = (aw[k] & 0xffffu) | (bw[k] << 16);
+            tileT[tc + 2 * k + 1][tp] = (aw[k] >> 16) | (bw[k] & 0xffff0000u);
+        }
     }
     __syncthreads();
+    constexpr int QPR = TR / 8;          // 16-B chunks per output row
+    constexpr int RPP = 256 / QPR;       // output rows per pass
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const int c = c0 + tr + p * 32, r = r0 + tc;  // output row = source column
+    for (int p = 0; p < 64 / RPP; ++p) {
+        const int cl = threadIdx.x / QPR + p * RPP;  // output row = source column
+        const int q = threadIdx.x % QPR;             // 8 source rows = 4 row pairs = 16 B
+        const int c = c0 + cl, r = r0 + q * 8;
         if (c < C && r < R) {
-            bf16x8 v;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = tile[tc + j][tr + p * 32];
-            *reinterpret_cast<bf16x8*>(dst + (size_t)c * R + r) = v;
+            const uint4 v = *reinterpret_cast<const uint4*>(&tileT[cl][q * 4]);
+            *reinterpret_cast<uint4*>(dst + (size_t)c * R + r) = v;
         }
     }
 }
@@ -1012,8 +1030,13 @@ extern "C" int mmu_embed_bwd(const long long* ids, const int* slot, const void* 
 // dst[C][R] = src[R][C]^T (R, C multiples of 8).  Used to keep W^T resident for the NT dgrad path.
 extern "C" int mmu_transpose_bf16(const void* src, void* dst, int R, int C, void* stream) {
     if (R <= 0 || C <= 0 || (R & 7) || (C & 7)) return -1;
-    hipLaunchKernelGGL(transpose_kernel, dim3((C + 63) / 64, (R + 63) / 64), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16*)src, (bf16*)dst, R, C);
+    if (R >= 4096) {  // long output rows: 256-row tiles (512-B output runs)
+        hipLaunchKernelGGL(transpose_kernel<256>, dim3((C + 63) / 64, (R + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16*)src, (bf16*)dst, R, C);
+    } else {
+        hipLaunchKernelGGL(transpose_kernel<64>, dim3((C + 63) / 64, (R + 63) / 64), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16*)src, (bf16*)dst, R, C);
+    }
     MMU_CHECK_LAUNCH();
     return 0;
 }
