@@ -31,7 +31,7 @@ import torch.distributed as dist  # noqa: E402
 PEAK_BF16 = 2.5e15  # dense bf16 MFMA FLOP/s per MI355X
 
 
-def flops_per_sample(cfg, S, paired=True, lora=False):
+def flops_per_sample(cfg, S, paired=True, lora=False, text_only=False, forward_only=False):
     """Algorithmic FLOPs of one grad_diff full-FT sample (forget + retain sequence), vision tower frozen:
     matmul = 2mnk, causal attention at half the dense S^2."""
     t, v = cfg.text, cfg.vision
@@ -44,7 +44,11 @@ def flops_per_sample(cfg, S, paired=True, lora=False):
     dv, iv = v.hidden_size, v.intermediate_size
     clip = cfg.vision_layers_used * (2 * T * (4 * dv * dv + 2 * dv * iv) + 2 * 2 * T * T * dv) + 2 * v.num_patches * v.patch_k * dv
     proj = 2 * v.num_patches * (dv * d + d * d)
+    if text_only:  # no image: neither the CLIP tower nor the projector runs
+        clip = proj = 0
     fwd = dec + clip + proj
+    if forward_only:  # one no-grad forward of one sequence (frozen teacher)
+        return fwd
     # LoRA: dgrad only (adapter GEMMs are < 1 %), including the dgrad sweep through the adapted CLIP tower (BASELINE.md
     # §2: 30.16 T per sequence); full fine-tuning: dgrad + wgrad of decoder and projector, CLIP frozen (no backward)
     fb = fwd + ((dec + proj + clip) if lora else 2 * (dec + proj))
@@ -248,6 +252,9 @@ def main():
     ap.add_argument("--gemm-persist", type=int, default=None, help="A/B: 256^2 GEMM launch mode (0 workgroup per tile, 1 persistent)")
     ap.add_argument("--gemm-tail-split", type=int, default=None, help="A/B: split-K tail of the 256^2 GEMM (0 off, 1 heuristic = default)")
     ap.add_argument("--keep-act-t", type=int, default=None, help="keep act^T from forward to backward (default: on when it costs <= 24 GB)")
+    ap.add_argument("--text-only", action="store_true",
+                    help="BASELINE config 1 surface on the GPU: the text trainer (nlp/dataloader.py) with tuple inputs "
+                         "[B,500], right-padded, no images (use with --lora-r 8 --loss grad_ascent)")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); gloo + --single-device "
                     "rehearses the N > 1 launch path on a 1-GPU box")
     ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
@@ -264,7 +271,7 @@ def main():
     from multimodal_unlearning_amd.engine import ForgetEngine, init_distributed
     from multimodal_unlearning_amd.llava import LlavaHIP
     from multimodal_unlearning_amd.synthetic import bench_batch, make_forget_batch
-    from multimodal_unlearning_amd.trainer import MMTrainerForgetting
+    from multimodal_unlearning_amd.trainer import CustomTrainerForgetting, MMTrainerForgetting
 
     if args.gemm_tail_split is not None:
         hip.gemm_set_tail_split(args.gemm_tail_split)
@@ -292,8 +299,12 @@ def main():
     needs_teacher = any(k in args.loss.lower() for k in ("kl", "npo", "scrub", "dpo", "llmu"))
     teacher = LlavaHIP(cfg, device=dev, init="device", seed=1, trainable=False) if needs_teacher else None
     splits = ("forget", "retain", "idk") if any(k in args.loss.lower() for k in ("idk", "dpo", "llmu")) else ("forget", "retain")
-    tr = MMTrainerForgetting(model=model, forget_loss=args.loss, teacher_model=teacher, loss_beta=1.0, l1_lambda=0.0,
-                             l0_lambda=0.0, l_norm_from="zero", loss_args={"fuse_pairs": not args.no_fuse})
+    if args.text_only:
+        tr = CustomTrainerForgetting(model=model, forget_loss=args.loss, oracle_model=teacher, loss_beta=1.0, l1_lambda=0.0,
+                                     l0_lambda=0.0, loss_args={"fuse_pairs": not args.no_fuse})
+    else:
+        tr = MMTrainerForgetting(model=model, forget_loss=args.loss, teacher_model=teacher, loss_beta=1.0, l1_lambda=0.0,
+                                 l0_lambda=0.0, l_norm_from="zero", loss_args={"fuse_pairs": not args.no_fuse})
     fcfg = ForgetConfig(batch_size=args.micro_batch, gradient_accumulation_steps=args.grad_accum)
     eng = ForgetEngine(model, tr, fcfg, total_steps=args.steps + args.warmup + 1, warmup_steps=1,
                        transposed_weights=not args.no_wt)
@@ -302,7 +313,17 @@ def main():
     n_seq = B * (2 if (len(splits) >= 2 and not args.no_fuse and args.loss.lower() in ("grad_diff_forget_ce_retain_ce", "eco_ft", "idk")) else 1)
     act_t_bytes = n_seq * (cfg.vision.num_patches + 512) * cfg.text.intermediate_size * 2 * cfg.text.num_layers
     model.keep_act_t = bool(args.keep_act_t) if args.keep_act_t is not None else (args.model == "7b" and act_t_bytes <= 24e9)
-    if args.model == "tiny":
+    if args.text_only:
+        from multimodal_unlearning_amd.synthetic import make_text_split
+
+        S = 64 if args.model == "tiny" else 500  # nlp/data_module.py: max_length 500, right padding
+        def text_mb(seed):
+            sp = [make_text_split(cfg, B, S, seed=seed * 10 + j, n_question=S // 4, right_pad=[(7 * b) % (S // 5) for b in range(B)],
+                                  device=dev) for j in range(len(splits))]
+            return [(s_["input_ids"], s_["labels"], s_["attention_mask"]) for s_ in sp]
+        mbs = [text_mb(1234 + rank * 100 + i) for i in range(GA)]
+        act_t_bytes = 0
+    elif args.model == "tiny":
         S = 64
         mbs = [make_forget_batch(cfg, B, S, seed=1234 + rank * 100 + i, n_question=8, splits=splits, device=dev)
                for i in range(GA)]
@@ -340,15 +361,11 @@ def main():
         value = samples / elapsed
         lt = args.loss.lower()
         paired = lt not in ("grad_ascent", "retain_ft", "npo")
-        fps = flops_per_sample(cfg, S, paired=paired, lora=bool(args.lora_r))
+        fps = flops_per_sample(cfg, S, paired=paired, lora=bool(args.lora_r), text_only=args.text_only)
         # teacher forwards (no grad): npo 1, kl 1, scrub 2, grad_diff_*_kl 1 per kl side
         t_fwd = {"npo": 1, "kl": 1, "scrub": 2, "llmu": 1}.get(lt, lt.count("_kl") if lt.startswith("grad_diff") else 0)
         if t_fwd:
-            # forward FLOPs of one sequence = fb_full - 2*(dec+proj) ; recover it from the two closed forms
-            full = flops_per_sample(cfg, S, paired=False, lora=False)
-            lo = flops_per_sample(cfg, S, paired=False, lora=True)
-            one_fwd = 2 * lo - full
-            fps += t_fwd * one_fwd
+            fps += t_fwd * flops_per_sample(cfg, S, text_only=args.text_only, forward_only=True)
         f, t, n, by = timer.summary()
         traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_gemm_traffic.json")
@@ -364,8 +381,11 @@ def main():
             "value": round(value, 4), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"LLaVA-1.5-{args.model} {args.loss} {'LoRA r=%d' % args.lora_r if args.lora_r else 'full-FT'} (CLIP frozen), S={S} (576 image + 512 text "
-                                   f"tokens), image 336, random-init weights", "micro_batch_pairs_per_gpu": B,
+            "config": {"workload": (f"LLaVA-1.5-{args.model} {args.loss} {'LoRA r=%d' % args.lora_r if args.lora_r else 'full-FT'} (CLIP frozen), S={S} (576 image + 512 text "
+                                    f"tokens), image 336, random-init weights") if not args.text_only else
+                                   (f"text trainer (nlp/dataloader.py surface) on the Llama-2-{args.model}-shaped decoder, {args.loss} "
+                                    f"{'LoRA r=%d' % args.lora_r if args.lora_r else 'full-FT'}, tuple inputs [B,{S}] right-padded, random-init weights"),
+                       "micro_batch_pairs_per_gpu": B,
                        "grad_accum": GA, "global_batch": world * B * GA, "seq_len": S, "parallelism": f"dp{world}",
                        "paired_fusion": not args.no_fuse, "optimizer": "AdamW fp32 moments, clip 1.0", "lora_r": args.lora_r,
                        "keep_act_t": model.keep_act_t,
