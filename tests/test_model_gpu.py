@@ -538,3 +538,50 @@ def test_l1l0_regulariser_hip_kernels(models):
         want = (0.25 * 0.5 * torch.sign(d.float())).to(torch.bfloat16)
         assert torch.equal(student.ensure_grad(), want), frm
     student.ensure_grad().zero_()
+
+
+def test_full_width_properties(dev):
+    """BASELINE.json's full sizes (LLaVA-1.5-7B widths: d 4096, I 11008, V 32064, 32 heads x 128, CLIP-L/14-336 with all
+    23 layers, S = 1088) with the decoder cut to 2 layers, checked through size-independent properties of the path:
+    paired fusion == separate forwards; exact linearity of the backward sweep in the upstream gradient (x2 is exact in
+    bf16); the loss == the per-sequence CE sums of the same logits / the number of supervised tokens; determinism."""
+    from multimodal_unlearning_amd.config import llava_1_5_7b
+    from multimodal_unlearning_amd.llava import LlavaHIP
+    from multimodal_unlearning_amd.synthetic import bench_batch
+    from multimodal_unlearning_amd.trainer import MMTrainerForgetting
+    from multimodal_unlearning_amd import trainer_utils as tu
+
+    cfg = llava_1_5_7b()
+    cfg.text.num_layers = 2
+    model = LlavaHIP(cfg, device=dev, init="device", seed=0)
+    batch = bench_batch(cfg, 2, seed=77, device=dev)
+    S = cfg.vision.num_patches + 512
+
+    def run(fuse, scale=1.0):
+        tr = MMTrainerForgetting(model=model, forget_loss="grad_diff_forget_ce_retain_ce", teacher_model=None, loss_beta=1.0,
+                                 l1_lambda=0, l0_lambda=0, l_norm_from="zero", loss_args={"fuse_pairs": fuse})
+        model.ensure_grad().zero_()
+        loss = tr.compute_loss(model, batch)
+        (loss * scale).backward()
+        return float(loss.detach()), model.ensure_grad().clone()
+
+    l_f, g_f = run(True)
+    l_u, g_u = run(False)
+    assert abs(l_f - l_u) <= 1e-3 * max(1.0, abs(l_u)), (l_f, l_u)
+    assert _relerr(g_f, g_u) < 2e-2, _relerr(g_f, g_u)  # bf16 accumulation order differs (one sweep vs two)
+    l_f2, g_f2 = run(True)
+    assert l_f2 == l_f  # same kernels, same data
+    _, g_x2 = run(True, scale=2.0)
+    # every kernel of the sweep is linear in the upstream gradient and a factor 2 commutes with bf16 rounding; the only
+    # non-associative pieces are the fp32 atomics of the embedding scatter
+    emb = slice(*model.range_of("text.embed_tokens.weight"))
+    mask = torch.ones_like(g_f, dtype=torch.bool)
+    mask[emb] = False
+    assert torch.equal(g_x2[mask], (2.0 * g_f2.float()).to(torch.bfloat16)[mask])
+    assert _relerr(g_x2[emb], 2.0 * g_f2[emb].float()) < 1e-3
+    with torch.no_grad():
+        out = model(**{k: v for k, v in batch["retain"].items()})
+    sums = tu.get_batch_loss(out.logits, batch["retain"]["labels"])
+    n_sup = int((batch["retain"]["labels"][:, 1:] != -100).sum())
+    assert abs(float(sums.sum()) / n_sup - float(out.loss)) < 2e-3 * float(out.loss)
+    assert out.logits.shape == (2, S, cfg.text.vocab_size)
