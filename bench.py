@@ -252,6 +252,8 @@ def main():
     ap.add_argument("--gemm-persist", type=int, default=None, help="A/B: 256^2 GEMM launch mode (0 workgroup per tile, 1 persistent)")
     ap.add_argument("--gemm-tail-split", type=int, default=None, help="A/B: split-K tail of the 256^2 GEMM (0 off, 1 heuristic = default)")
     ap.add_argument("--keep-act-t", type=int, default=None, help="keep act^T from forward to backward (default: on when it costs <= 24 GB)")
+    ap.add_argument("--optim", default="adamw", choices=["adamw", "adamw8bit"],
+                    help="adamw: fp32 moments; adamw8bit: block-wise 8-bit moments (the reference's adamw_bnb_8bit)")
     ap.add_argument("--text-only", action="store_true",
                     help="BASELINE config 1 surface on the GPU: the text trainer (nlp/dataloader.py) with tuple inputs "
                          "[B,500], right-padded, no images (use with --lora-r 8 --loss grad_ascent)")
@@ -307,7 +309,7 @@ def main():
                                  l0_lambda=0.0, l_norm_from="zero", loss_args={"fuse_pairs": not args.no_fuse})
     fcfg = ForgetConfig(batch_size=args.micro_batch, gradient_accumulation_steps=args.grad_accum)
     eng = ForgetEngine(model, tr, fcfg, total_steps=args.steps + args.warmup + 1, warmup_steps=1,
-                       transposed_weights=not args.no_wt)
+                       transposed_weights=not args.no_wt, optimizer=args.optim)
 
     B, GA = args.micro_batch, args.grad_accum
     n_seq = B * (2 if (len(splits) >= 2 and not args.no_fuse and args.loss.lower() in ("grad_diff_forget_ce_retain_ce", "eco_ft", "idk")) else 1)
@@ -387,7 +389,9 @@ def main():
                                     f"{'LoRA r=%d' % args.lora_r if args.lora_r else 'full-FT'}, tuple inputs [B,{S}] right-padded, random-init weights"),
                        "micro_batch_pairs_per_gpu": B,
                        "grad_accum": GA, "global_batch": world * B * GA, "seq_len": S, "parallelism": f"dp{world}",
-                       "paired_fusion": not args.no_fuse, "optimizer": "AdamW fp32 moments, clip 1.0", "lora_r": args.lora_r,
+                       "paired_fusion": not args.no_fuse,
+                       "optimizer": ("AdamW fp32 moments" if args.optim == "adamw" else "AdamW block-wise 8-bit moments") + ", clip 1.0",
+                       "lora_r": args.lora_r,
                        "keep_act_t": model.keep_act_t,
                        "decoder_layers": cfg.text.num_layers},
             "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 1e9, 1),

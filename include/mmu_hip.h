@@ -171,6 +171,15 @@ int mmu_sumsq_scratch_floats(void);
 int mmu_adamw_bf16(void* p, void* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
                    float weight_decay, int step, const float* sumsq, float max_norm, float grad_scale, int zero_grad,
                    void* stream);
+/* AdamW with block-wise 8-bit moments (the reference's optim="adamw_bnb_8bit", mm/forget.py:156; bitsandbytes is not in
+ * /root/reference: published algorithm restated, parity unpinned): blocks of 2048 parameters, 8-bit codes of a
+ * 256-entry dynamic quantisation map (map1 signed for m, map2 unsigned for v; device pointers) times an fp32 absmax
+ * per block.  codes*: n bytes each; absmax*: mmu_adamw8bit_nblocks(n) floats each.  Fresh state: codes = index of
+ * 0.0 in the map, absmax = 0.  Same clip / grad_scale / zero_grad semantics as mmu_adamw_bf16. */
+int mmu_adamw8bit_nblocks(long long n);
+int mmu_adamw8bit_bf16(void* p, void* g, void* codes1, void* codes2, float* absmax1, float* absmax2, const float* map1,
+                       const float* map2, long long n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                       int step, const float* sumsq, float max_norm, float grad_scale, int zero_grad, void* stream);
 int mmu_scale_bf16(void* x, long long n, float s, void* stream);
 
 #ifdef __cplusplus

@@ -107,7 +107,8 @@ class ForgetEngine:
     """engine.step(micro_batches) = GA x (compute_loss -> backward) -> all-reduce -> clip -> AdamW -> zero grads."""
 
     def __init__(self, model, trainer, cfg: ForgetConfig, total_steps: int = 1000, warmup_steps: int = 0,
-                 group=None, transposed_weights: bool = True, force_collectives: bool = False):
+                 group=None, transposed_weights: bool = True, force_collectives: bool = False,
+                 optimizer: str = "adamw"):
         from . import hip  # HIP optimiser kernels; fails loudly when the library is missing
 
         self.hip = hip
@@ -118,8 +119,24 @@ class ForgetEngine:
         dev = model.device
         self.grad = model.ensure_grad()
         n = self.grad.numel()
-        self.m = torch.zeros(n, device=dev, dtype=torch.float32)
-        self.v = torch.zeros(n, device=dev, dtype=torch.float32)
+        # "adamw": fp32 moments (8 B/param).  "adamw8bit": block-wise 8-bit moments as in the reference's
+        # optim="adamw_bnb_8bit" (mm/forget.py:156): 2 B/param + one fp32 absmax per 2048 parameters and moment.
+        if optimizer not in ("adamw", "adamw8bit"):
+            raise ValueError(f"unknown optimizer {optimizer}")
+        self.optimizer = optimizer
+        if optimizer == "adamw":
+            self.m = torch.zeros(n, device=dev, dtype=torch.float32)
+            self.v = torch.zeros(n, device=dev, dtype=torch.float32)
+        else:
+            self.map1 = hip.dynamic_map(True).to(dev)
+            self.map2 = hip.dynamic_map(False).to(dev)
+            zero1 = int((self.map1 == 0).nonzero()[0])
+            zero2 = int((self.map2 == 0).nonzero()[0])
+            self.c1 = torch.full((n,), zero1, device=dev, dtype=torch.uint8)
+            self.c2 = torch.full((n,), zero2, device=dev, dtype=torch.uint8)
+            nb = hip.adamw8bit_nblocks(n)
+            self.am1 = torch.zeros(nb, device=dev, dtype=torch.float32)
+            self.am2 = torch.zeros(nb, device=dev, dtype=torch.float32)
         self.sumsq = torch.zeros(hip.SUMSQ_FLOATS, device=dev, dtype=torch.float32)  # [0] = |g|^2, rest scratch
         self.opt_step = 0
         self.reducer = GradBucketReducer(self.grad, group, force=force_collectives)
@@ -144,9 +161,14 @@ class ForgetEngine:
         self.opt_step += 1
         lr = linear_schedule(self.opt_step, self.cfg.lr, self.warmup_steps, self.total_steps)
         self.hip.sumsq(self.grad, self.sumsq)
-        self.hip.adamw(model.train_flat.data, self.grad, self.m, self.v, lr, self.cfg.adam_beta1, self.cfg.adam_beta2,
-                       self.cfg.adam_eps, self.cfg.weight_decay, self.opt_step, self.sumsq, self.cfg.max_grad_norm,
-                       1.0 / self.world, True)
+        if self.optimizer == "adamw":
+            self.hip.adamw(model.train_flat.data, self.grad, self.m, self.v, lr, self.cfg.adam_beta1, self.cfg.adam_beta2,
+                           self.cfg.adam_eps, self.cfg.weight_decay, self.opt_step, self.sumsq, self.cfg.max_grad_norm,
+                           1.0 / self.world, True)
+        else:
+            self.hip.adamw8bit(model.train_flat.data, self.grad, self.c1, self.c2, self.am1, self.am2, self.map1, self.map2,
+                               lr, self.cfg.adam_beta1, self.cfg.adam_beta2, self.cfg.adam_eps, self.cfg.weight_decay,
+                               self.opt_step, self.sumsq, self.cfg.max_grad_norm, 1.0 / self.world, True)
         model.refresh_derived()  # W^T copies (full fine-tuning) or LoRA's scaled / transposed adapter copies
         mean_loss = (total / ga)
         if sync_loss:

@@ -74,6 +74,8 @@ SIGNATURES = {
     "mmu_sumsq_bf16": [_vp, _ll, _vp, _vp],
     "mmu_sumsq_scratch_floats": [],
     "mmu_adamw_bf16": [_vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _f, _i, _vp, _f, _f, _i, _vp],
+    "mmu_adamw8bit_nblocks": [_ll],
+    "mmu_adamw8bit_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _f, _i, _vp, _f, _f, _i, _vp],
     "mmu_scale_bf16": [_vp, _ll, _f, _vp],
 }
 
@@ -504,6 +506,40 @@ def adamw(p, g, m, v, lr, beta1, beta2, eps, wd, step, sumsq_t, max_norm, grad_s
     _check(load().mmu_adamw_bf16(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, wd, step,
                                  _p(sumsq_t), float(max_norm), float(grad_scale), int(zero_grad), _stream()),
            "mmu_adamw_bf16")
+
+
+def dynamic_map(signed: bool, max_exponent_bits: int = 7, total_bits: int = 8) -> torch.Tensor:
+    """The 256-entry dynamic (tree) quantisation map of block-wise 8-bit optimizers (Dettmers et al. 2021; bitsandbytes
+    `create_dynamic_map`): for exponent i the interval [0.1, 1] * 10^(i - 6) is cut into 2^i (signed) or 2^(i+1)
+    (unsigned) equal pieces whose mid-points are the codes, plus 0 and 1; sorted ascending."""
+    non_sign_bits = total_bits - 1
+    data = []
+    for i in range(max_exponent_bits):
+        items = (2 ** (i + non_sign_bits - max_exponent_bits) + 1) if signed else (2 ** (i + non_sign_bits - max_exponent_bits + 1) + 1)
+        b = torch.linspace(0.1, 1, items)
+        means = (b[:-1] + b[1:]) / 2.0
+        vals = (10.0 ** (-(max_exponent_bits - 1) + i)) * means
+        data += vals.tolist()
+        if signed:
+            data += (-vals).tolist()
+    data += [0.0, 1.0]
+    assert len(data) == 2 ** total_bits, len(data)
+    return torch.tensor(sorted(data), dtype=torch.float32)
+
+
+def adamw8bit_nblocks(n: int) -> int:
+    return load().mmu_adamw8bit_nblocks(int(n))
+
+
+def adamw8bit(p, g, codes1, codes2, absmax1, absmax2, map1, map2, lr, beta1, beta2, eps, wd, step, sumsq_t, max_norm,
+              grad_scale=1.0, zero_grad=True):
+    _bf16c(p, g)
+    assert codes1.dtype == torch.uint8 and codes2.dtype == torch.uint8 and codes1.numel() == p.numel() == codes2.numel()
+    assert absmax1.dtype == torch.float32 and absmax1.numel() >= adamw8bit_nblocks(p.numel()) == adamw8bit_nblocks(p.numel())
+    assert map1.numel() == 256 and map2.numel() == 256 and map1.is_cuda and map2.is_cuda
+    _check(load().mmu_adamw8bit_bf16(_p(p), _p(g), _p(codes1), _p(codes2), _p(absmax1), _p(absmax2), _p(map1), _p(map2),
+                                     p.numel(), lr, beta1, beta2, eps, wd, step, _p(sumsq_t), float(max_norm),
+                                     float(grad_scale), int(zero_grad), _stream()), "mmu_adamw8bit_bf16")
 
 
 def scale_(x, s):
