@@ -379,7 +379,11 @@ def main():
             pj = json.load(open(pmc))
             traffic, traffic_src = round(pj["traffic_bytes_per_launch"]), "profiles/r01_pmc_gemm_traffic.json"
         out = {
-            "metric": "forget-step samples/sec (img+text pairs) LLaVA-1.5-7B grad_diff",
+            # BASELINE.json's metric for the default workload; other configs name themselves
+            "metric": ("forget-step samples/sec (img+text pairs) LLaVA-1.5-7B grad_diff"
+                       if (args.model == "7b" and args.loss == "grad_diff_forget_ce_retain_ce" and not args.lora_r and not args.text_only)
+                       else f"forget-step samples/sec {'text-only ' if args.text_only else ''}LLaVA-1.5-{args.model} {args.loss}"
+                            f"{' LoRA r=%d' % args.lora_r if args.lora_r else ''}"),
             "value": round(value, 4), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
