@@ -249,6 +249,7 @@ def main():
     ap.add_argument("--loss", default="grad_diff_forget_ce_retain_ce")
     ap.add_argument("--layers", type=int, default=0, help="debug: override decoder depth (invalidates the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gemm-group-m", type=int, default=None, help="A/B: GROUP_M rasterisation of the 256^2 GEMM (default 4)")
     ap.add_argument("--gemm-persist", type=int, default=None, help="A/B: 256^2 GEMM launch mode (0 workgroup per tile, 1 persistent)")
     ap.add_argument("--gemm-tail-split", type=int, default=None, help="A/B: split-K tail of the 256^2 GEMM (0 off, 1 heuristic = default)")
     ap.add_argument("--keep-act-t", type=int, default=None, help="keep act^T from forward to backward (default: on when it costs <= 24 GB)")
@@ -277,6 +278,8 @@ def main():
 
     if args.gemm_tail_split is not None:
         hip.gemm_set_tail_split(args.gemm_tail_split)
+    if args.gemm_group_m is not None:
+        hip.gemm_set_group_m(args.gemm_group_m)
     if args.gemm_persist is not None:
         hip.gemm_set_persistent(args.gemm_persist)
     if os.environ.get("MMU_DUMP_AFTER"):  # debugging aid for rehearsals: dump every thread's stack and exit
