@@ -540,19 +540,23 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
                 f32x16 s, dp;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-                {
-                    bf16x8 kf[NKS], vf[NKS];
 #pragma unroll
-                    for (int ks = 0; ks < NKS; ++ks) {
-                        kf[ks] = *(const MMU_LDS bf16x8*)(kt + st * 32 * (D * 2) + fo.row[ks]);
-                        vf[ks] = *(const MMU_LDS bf16x8*)(vt + st * 32 * (D * 2) + fo.row[ks]);
+                for (int h4 = 0; h4 < NKS; h4 += 4) {
+                    // 4 K and 4 V fragments per batch (32 registers): all 8 + 8 at once pushed the kernel past 256
+                    // VGPRs, and scratch reloads inside this loop queue behind the LDS-DMA on vmcnt
+                    bf16x8 kf[4], vf[4];
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        kf[ks] = *(const MMU_LDS bf16x8*)(kt + st * 32 * (D * 2) + fo.row[h4 + ks]);
+                        vf[ks] = *(const MMU_LDS bf16x8*)(vt + st * 32 * (D * 2) + fo.row[h4 + ks]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int ks = 0; ks < NKS; ++ks) {
-                        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], s, 0, 0, 0);
-                        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[ks], dof[ks], dp, 0, 0, 0);
+                    for (int ks = 0; ks < 4; ++ks) {
+                        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[h4 + ks], s, 0, 0, 0);
+                        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[ks], dof[h4 + ks], dp, 0, 0, 0);
                     }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -700,27 +704,33 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
             f32x16 s, dp;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-            {   // S[q][key] = Q K^T
-                bf16x8 fa[NKS], fb[NKS];
+            // S[q][key] = Q K^T and dP[q][key] = dO V^T in batches of 4 k-steps: with the 128 dK^T / dV^T accumulators
+            // resident, 8 + 8 fragments at once spilled (132 B of scratch, reloads queue on vmcnt behind the LDS-DMA)
 #pragma unroll
-                for (int ks = 0; ks < NKS; ++ks) {
-                    fa[ks] = *(const MMU_LDS bf16x8*)(qtile + off_row[ks]);
-                    fb[ks] = *(const MMU_LDS bf16x8*)(ktile + off_row[ks]);
-                }
-                __builtin_amdgcn_sched_barrier(0);  // all 16 reads in flight before the first MFMA waits
+            for (int h4 = 0; h4 < NKS; h4 += 4) {
+                bf16x8 fa[4], fb[4];
 #pragma unroll
-                for (int ks = 0; ks < NKS; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks], fb[ks], s, 0, 0, 0);
-            }
-            {   // dP[q][key] = dO V^T
-                bf16x8 fa[NKS], fb[NKS];
-#pragma unroll
-                for (int ks = 0; ks < NKS; ++ks) {
-                    fa[ks] = *(const MMU_LDS bf16x8*)(dotile + off_row[ks]);
-                    fb[ks] = *(const MMU_LDS bf16x8*)(vtile + off_row[ks]);
+                for (int ks = 0; ks < 4; ++ks) {
+                    fa[ks] = *(const MMU_LDS bf16x8*)(qtile + off_row[h4 + ks]);
+                    fb[ks] = *(const MMU_LDS bf16x8*)(ktile + off_row[h4 + ks]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int ks = 0; ks < NKS; ++ks) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks], fb[ks], dp, 0, 0, 0);
+                for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks], fb[ks], s, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int h4 = 0; h4 < NKS; h4 += 4) {
+                bf16x8 fa[4], fb[4];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    fa[ks] = *(const MMU_LDS bf16x8*)(dotile + off_row[h4 + ks]);
+                    fb[ks] = *(const MMU_LDS bf16x8*)(vtile + off_row[h4 + ks]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks], fb[ks], dp, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
             const bool diag = CAUSAL && (q_first < key0 + 31);
 #pragma unroll
