@@ -782,3 +782,21 @@ def test_adamw8bit_blockwise(dev):
         pr = p.cpu().clone()
     # 8-bit moments track the fp32-moment trajectory
     assert _relerr(p.float(), pf.float()) < 2e-2
+
+
+def test_c_abi_from_a_native_caller(dev, tmp_path):
+    """The boundary is a C ABI: a torch-free C++ program (tests/c_abi/gemm_caller.cpp) built with hipcc against
+    include/mmu_hip.h and libmmu_hip.so runs the GEMM entry point and checks it exactly."""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "multimodal_unlearning_amd", "csrc")
+    exe = str(tmp_path / "gemm_caller")
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-I", os.path.join(root, "include"),
+                    os.path.join(root, "tests", "c_abi", "gemm_caller.cpp"), "-L", libdir, "-lmmu_hip",
+                    f"-Wl,-rpath,{libdir}", "-o", exe], check=True, capture_output=True, timeout=300)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert "c-abi caller ok" in r.stdout
