@@ -250,7 +250,7 @@ def main():
     ap.add_argument("--layers", type=int, default=0, help="debug: override decoder depth (invalidates the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gemm-group-m", type=int, default=None, help="A/B: GROUP_M rasterisation of the 256^2 GEMM (default 4)")
-    ap.add_argument("--gemm-persist", type=int, default=None, help="A/B: 256^2 GEMM launch mode (0 workgroup per tile, 1 persistent)")
+    ap.add_argument("--gemm-persist", type=int, default=None, help="A/B: 256^2 GEMM launch mode (0 workgroup per tile, 1 persistent = default)")
     ap.add_argument("--gemm-tail-split", type=int, default=None, help="A/B: split-K tail of the 256^2 GEMM (0 off, 1 heuristic = default)")
     ap.add_argument("--keep-act-t", type=int, default=None, help="keep act^T from forward to backward (default: on when it costs <= 24 GB)")
     ap.add_argument("--optim", default="adamw", choices=["adamw", "adamw8bit"],

@@ -52,8 +52,8 @@ int mmu_fold_f32_into_bf16(float* src32, void* dst, const void* mask, long long 
 int mmu_gemm_set_tile(int tile);
 /* Tile rasterisation of the 256x256 kernel (tuning): GROUP_M tile rows swept column by column; 0 = default. */
 int mmu_gemm_set_group_m(int group_m);
-/* 256x256 kernel launch mode (A/B tests): 0 = one workgroup per tile (default); 1 = persistent, 256 workgroups walk
- * the tiles. */
+/* 256x256 kernel launch mode: 1 = persistent, 256 workgroups walk the tiles (default); 0 = one workgroup per tile
+ * (A/B tests). */
 int mmu_gemm_set_persistent(int mode);
 /* Split-K tail of the 256x256 kernel: when the last (tiles % 256) tiles fill at most half a round of the 256 CUs, each
  * is cut into 256 / remainder K ranges on extra workgroups (fp32 partials in the workspace, reduced by a fold

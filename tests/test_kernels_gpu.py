@@ -659,7 +659,7 @@ def test_gemm256_persistent_launch_matches(dev):
         assert torch.equal(outs[0][1], ((ref + bias.float()).to(BF).float() + resid.float()).to(BF))
         assert torch.equal(outs[0][2], (ref + resid.float()).to(BF))
     finally:
-        hip.gemm_set_persistent(0)
+        hip.gemm_set_persistent(1)  # the default
         hip.gemm_set_tile(0)
 
 
