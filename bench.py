@@ -235,6 +235,23 @@ def hbm_kernels(hip, cfg, n_seq, S, dev, reps=5):
     return out
 
 
+def launch_ranks(n: int, argv) -> int:
+    """One child process per GPU through torch.distributed.run on 127.0.0.1 (free port), same arguments."""
+    import socket
+    import subprocess
+
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this image
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -263,11 +280,21 @@ def main():
     ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--hbm-kernels", action="store_true",
                     help="also time the step's HBM-bound kernels standalone (bytes next to GB/s) after the timed region")
+    ap.add_argument("--dp-mode", default="allreduce", choices=["allreduce", "rs_ag"],
+                    help="gradient exchange at N > 1: bucketed all-reduce overlapped with backward (default), or "
+                         "reduce-scatter + sharded AdamW state + parameter all-gather (ZeRO-style, state / N)")
     ap.add_argument("--no-fuse", action="store_true")
     ap.add_argument("--no-wt", action="store_true", help="do not keep resident W^T copies (saves one weight copy of HBM)")
     ap.add_argument("--lora-r", type=int, default=0, help="LoRA rank (0 = full fine-tuning); BASELINE config 2 uses 8")
     ap.add_argument("--lora-alpha", type=float, default=32.0)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` as the driver invokes it: start the N ranks as fresh processes (one per GPU,
+        # torch.distributed.run = what `accelerate launch` does for the reference, run_exps.py:36) BEFORE this process
+        # loads the HIP library or touches a GPU — never re-exec a GPU-initialised process.  Rank 0's JSON line goes to
+        # the inherited stdout; the parent only forwards the exit code.
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     from multimodal_unlearning_amd import hip
     from multimodal_unlearning_amd.config import ForgetConfig, llava_1_5_7b, llava_1_5_13b, tiny_test_config
@@ -312,7 +339,7 @@ def main():
                                  l0_lambda=0.0, l_norm_from="zero", loss_args={"fuse_pairs": not args.no_fuse})
     fcfg = ForgetConfig(batch_size=args.micro_batch, gradient_accumulation_steps=args.grad_accum)
     eng = ForgetEngine(model, tr, fcfg, total_steps=args.steps + args.warmup + 1, warmup_steps=1,
-                       transposed_weights=not args.no_wt, optimizer=args.optim)
+                       transposed_weights=not args.no_wt, optimizer=args.optim, dp_mode=args.dp_mode)
 
     B, GA = args.micro_batch, args.grad_accum
     n_seq = B * (2 if (len(splits) >= 2 and not args.no_fuse and args.loss.lower() in ("grad_diff_forget_ce_retain_ce", "eco_ft", "idk")) else 1)
@@ -345,6 +372,7 @@ def main():
     for _ in range(args.warmup):
         eng.step(mbs)
     sync()
+    eng.time_exchange = world > 1
     t0 = time.perf_counter()
     timer = None
     for k in range(args.steps):
@@ -356,10 +384,16 @@ def main():
             eng.step(mbs)
     sync()
     elapsed = time.perf_counter() - t0
-    tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    # per-rank wall time of the timed region and the exposed part of the gradient exchange (compute stream idle between
+    # the end of the last backward sweep and the last collective's completion), gathered so that one line carries them
+    exch_ms = sum(a.elapsed_time(b) for a, b in eng.exchange_events) / max(1, len(eng.exchange_events))
+    mine = torch.tensor([elapsed, exch_ms], device=dev, dtype=torch.float64)
+    per_rank = [mine.clone() for _ in range(world)]
     if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed = float(tmax.item())
+        dist.all_gather(per_rank, mine)
+    rank_elapsed = [float(t[0]) for t in per_rank]
+    rank_exch_ms = [float(t[1]) for t in per_rank]
+    elapsed = max(rank_elapsed)
 
     if rank == 0:
         samples = world * B * GA * args.steps
@@ -372,15 +406,23 @@ def main():
         if t_fwd:
             fps += t_fwd * flops_per_sample(cfg, S, text_only=args.text_only, forward_only=True)
         f, t, n, by = timer.summary()
+        # HBM-side bytes per GEMM launch (rocprofv3 PMC: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate passes; counts L2
+        # misses incl. Infinity-Cache hits).  PMC collection cannot run inside the timed process, so the figure is
+        # collected OFFLINE by tools/pmc_bench_traffic.sh on this same workload and is reported only when that file was
+        # made from the GEMM source this library was built from (sha256 of csrc/gemm.hip); otherwise null.
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_gemm_traffic.json")
-        if os.path.exists(pmc) and args.model == "7b" and args.loss == "grad_diff_forget_ce_retain_ce" and not args.lora_r \
-                and args.micro_batch == 15:
-            # HBM-side bytes per GEMM launch from rocprofv3 PMC passes of this same workload (FETCH_SIZE x2 on gfx950 +
-            # WRITE_SIZE, separate passes; counts L2 misses incl. Infinity-Cache hits) — collected offline by
-            # tools/pmc_bench_traffic.sh, because PMC collection cannot run inside the timed process
-            pj = json.load(open(pmc))
-            traffic, traffic_src = round(pj["traffic_bytes_per_launch"]), "profiles/r01_pmc_gemm_traffic.json"
+        default_wl = (args.model == "7b" and args.loss == "grad_diff_forget_ce_retain_ce" and not args.lora_r
+                      and args.micro_batch == 15 and not args.text_only)
+        if default_wl:
+            import glob
+            import hashlib
+            sha = hashlib.sha256(open(os.path.join(ROOT, "multimodal_unlearning_amd", "csrc", "gemm.hip"), "rb").read()).hexdigest()[:16]
+            for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_gemm_traffic.json")), reverse=True):
+                pj = json.load(open(pmc))
+                if pj.get("gemm_src_sha16") == sha:
+                    traffic = round(pj["traffic_bytes_per_launch"])
+                    traffic_src = {"collected": "offline", "file": os.path.relpath(pmc, ROOT), "gemm_src_sha16": sha}
+                    break
         out = {
             # BASELINE.json's metric for the default workload; other configs name themselves
             "metric": ("forget-step samples/sec (img+text pairs) LLaVA-1.5-7B grad_diff"
@@ -401,6 +443,10 @@ def main():
                        "lora_r": args.lora_r,
                        "keep_act_t": model.keep_act_t,
                        "decoder_layers": cfg.text.num_layers},
+            "per_rank_samples_per_s": [round(B * GA * args.steps / t_, 4) for t_ in rank_elapsed],
+            "dp": {"mode": args.dp_mode if world > 1 else None, "backend": (dist.get_backend() if world > 1 else None),
+                   "gradient_bytes_per_step": model.train_flat.numel() * 2,
+                   "exposed_exchange_ms_per_step": [round(x, 2) for x in rank_exch_ms] if world > 1 else None},
             "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 1e9, 1),
             "step_tflops_per_gpu": round(value * fps / world / 1e12, 1),
             "step_frac_of_mfma_peak": round(value * fps / world / PEAK_BF16, 4),

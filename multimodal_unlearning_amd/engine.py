@@ -25,7 +25,10 @@ from .config import ForgetConfig
 
 
 def linear_schedule(step: int, base_lr: float, warmup_steps: int, total_steps: int) -> float:
-    """transformers get_linear_schedule_with_warmup evaluated at optimiser step `step` (0-based)."""
+    """base_lr * lambda(step) of transformers' get_linear_schedule_with_warmup.  HF's LambdaLR steps AFTER the
+    optimiser, so the k-th update (k = 1, 2, ...) runs at lambda(k - 1): the first update of a warm-up has lr 0 and
+    the last update of the run still has a positive lr.  ForgetEngine.step evaluates this at the number of updates
+    already done (tests/test_dp_gloo_cpu.py pins the sequence against torch's LambdaLR)."""
     if step < warmup_steps:
         return base_lr * step / max(1, warmup_steps)
     return base_lr * max(0.0, (total_steps - step) / max(1, total_steps - warmup_steps))
@@ -43,57 +46,166 @@ def shard_indices(n: int, rank: int, world: int) -> List[int]:
 
 
 class GradBucketReducer:
-    """Asynchronous SUM all-reduce of [lo,hi) ranges of one flat gradient tensor.  Works on CPU (gloo) and GPU."""
+    """Asynchronous gradient exchange over one flat gradient tensor.  Works on CPU (gloo) and GPU (RCCL).
 
-    def __init__(self, flat_grad: torch.Tensor, group=None, max_bucket_elems: int = 1 << 28, force: bool = False):
-        self.flat = flat_grad
-        self.group = group
-        self.max_bucket = max_bucket_elems
-        self.works = []
-        self.reduced_elems = 0
-        self.done = []  # [lo, hi) intervals already handed to a collective in this step
+    The buffer is cut ONCE into a fixed grid of buckets (`bucket_elems` each; boundaries are multiples of 8 * world so a
+    bucket splits into equal per-rank shards).  The model's backward sweep reports element ranges [lo,hi) that are
+    final (`mark_final`); a bucket's collective starts as soon as the bucket is fully covered.  Collectives are issued
+    in ONE canonical order on every rank — strictly descending bucket index, the order the top-down sweep completes
+    them — whatever the order of the hook calls, and the ranges reported within one step must be disjoint (an
+    overlapping report means a bucket was handed over before its last writer ran: the multi-sweep bug of round 1).
+
+    mode "allreduce": SUM all-reduce of every bucket; each rank then runs the whole optimiser step (replicas).
+    mode "rs_ag"    : SUM reduce-scatter of every bucket into the rank's own shard (in place); the owner of the step
+                      updates only its shards and `gather_params` all-gathers the updated parameter buckets — the
+                      reduce-scatter / sharded-optimiser-state / all-gather scheme of the reference's ZeRO config
+                      (config/ds_config.json:2-21).  Elements past the last full world*8 multiple go through a small
+                      all-reduce and are updated on every rank.
+    """
+
+    def __init__(self, flat_grad: torch.Tensor, group=None, bucket_elems: int = 1 << 27, force: bool = False,
+                 mode: str = "allreduce", max_inflight: Optional[int] = None):
+        if mode not in ("allreduce", "rs_ag"):
+            raise ValueError(f"unknown DP mode {mode}")
+        self.flat, self.group, self.mode = flat_grad, group, mode
         # force=True runs the collectives even on a 1-rank group (exercises the RCCL path on a single GPU)
         self.enabled = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force)
+        self.world = dist.get_world_size(group) if self.enabled else 1
+        self.rank = dist.get_rank(group) if self.enabled else 0
         self._gloo = self.enabled and dist.get_backend(group) == "gloo"
+        # gloo runs async works on a 2-thread pool per process; see DESIGN.md §6 for why at most `max_inflight` works
+        # are kept outstanding there (RCCL is stream-ordered: any number may be in flight)
+        self.max_inflight = max_inflight if max_inflight is not None else (2 if self._gloo else 0)
+        n = flat_grad.numel()
+        q = 8 * self.world
+        step = max(q, bucket_elems // q * q)
+        body = n // q * q  # elements that split evenly into per-rank shards of whole 16-byte groups
+        self.buckets = [(lo, min(lo + step, body)) for lo in range(0, body, step)]
+        self.tail = (body, n) if body < n else None
+        self.works = []
+        self.issued = []  # bucket indices in issue order (tests / debugging: must be identical on every rank)
+        self._cov = []    # disjoint, sorted [lo,hi) intervals reported final in this step
+        self._next = len(self.buckets) - 1
+        self._tail_done = False
+        self.reduced_elems = 0
 
-    def reduce_range(self, lo: int, hi: int):
-        if not self.enabled:
+    # -- coverage ---------------------------------------------------------------------------------------------
+    def _covered(self, lo, hi):
+        for a, b in self._cov:
+            if a <= lo and hi <= b:
+                return True
+        return False
+
+    def mark_final(self, lo: int, hi: int):
+        """Hook target: elements [lo,hi) of the gradient are final for this step."""
+        if not self.enabled or lo >= hi:
             return
-        self.done.append((lo, hi))
-        while lo < hi:
-            e = min(hi, lo + self.max_bucket)
-            # RCCL runs the buckets in stream order, any number may be in flight.  gloo (CPU plumbing mode, rehearsals)
-            # executes async works on a small thread pool: with >= 4 ranks and many works in flight the ranks' pools
-            # pick different buckets and wait for each other forever (seen with 4 ranks on one GPU) -> at most 2 there.
-            if self._gloo and len(self.works) >= 2:
-                self.works.pop(0).wait()
-            self.works.append(dist.all_reduce(self.flat[lo:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-            self.reduced_elems += e - lo
-            lo = e
+        for a, b in self._cov:
+            if lo < b and a < hi:
+                raise RuntimeError(f"gradient range [{lo},{hi}) overlaps [{a},{b}) already reported final in this step")
+        self._cov.append((lo, hi))
+        self._cov.sort()
+        merged = []
+        for a, b in self._cov:
+            if merged and merged[-1][1] == a:
+                merged[-1] = (merged[-1][0], b)
+            else:
+                merged.append((a, b))
+        self._cov = merged
+        self._issue_ready()
+
+    reduce_range = mark_final  # round-1 name
+
+    def _issue_ready(self):
+        if self.tail is not None and not self._tail_done and self._covered(*self.tail):
+            self._issue(self.tail, tail=True)
+        while self._next >= 0 and (self._tail_done or self.tail is None) and self._covered(*self.buckets[self._next]):
+            self._issue(self.buckets[self._next], idx=self._next)
+            self._next -= 1
+
+    def _issue(self, rng, idx=-1, tail=False):
+        lo, hi = rng
+        if self.max_inflight and len(self.works) >= self.max_inflight:
+            self.works.pop(0).wait()
+        buf = self.flat[lo:hi]
+        if tail or self.mode == "allreduce":
+            w = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            sz = (hi - lo) // self.world
+            out = buf[self.rank * sz:(self.rank + 1) * sz]  # in place: recv = send + rank * count (RCCL's in-place form)
+            if self._gloo:  # gloo's reduce_scatter is not specified for aliased buffers: go through a copy
+                tmp = torch.empty_like(out)
+                w = dist.reduce_scatter_tensor(tmp, buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                w = _CopyAfter(w, tmp, out)
+            else:
+                w = dist.reduce_scatter_tensor(out, buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.works.append(w)
+        self.issued.append(-1 if tail else idx)
+        self.reduced_elems += hi - lo
+        if tail:
+            self._tail_done = True
 
     def reduce_rest(self):
-        """All-reduce whatever no hook covered (a loss whose last sweep never ran — dead forwards keep the model's
-        live-sweep count above zero — or a model without hooks): the complement of the intervals seen so far."""
+        """Issue whatever no hook covered (a loss whose last sweep never ran — dead forwards keep the model's live-sweep
+        count above zero — or a model without hooks), in the same canonical order."""
         if not self.enabled:
             return
-        pos, n, gaps = 0, self.flat.numel(), []
-        for lo, hi in sorted(self.done):
-            if lo > pos:
-                gaps.append((pos, lo))
-            pos = max(pos, hi)
-        if pos < n:
-            gaps.append((pos, n))
-        for lo, hi in gaps:
-            self.reduce_range(lo, hi)
+        self._cov = [(0, self.flat.numel())]
+        self._issue_ready()
 
     def wait(self):
-        self.done = []
         for w in self.works:
             w.wait()
         self.works = []
+        self._cov = []
+        self._next = len(self.buckets) - 1
+        self._tail_done = False
+        self.issued = []
         n = self.reduced_elems
         self.reduced_elems = 0
         return n
+
+    # -- rs_ag: the shards this rank owns, and the parameter all-gather -------------------------------------------
+    def shard_ranges(self):
+        """[lo,hi) element ranges whose optimiser state this rank owns (rs_ag: one shard per bucket + the replicated
+        tail; allreduce: everything)."""
+        if not self.enabled or self.mode == "allreduce":
+            return [(0, self.flat.numel())]
+        out = []
+        for lo, hi in self.buckets:
+            sz = (hi - lo) // self.world
+            out.append((lo + self.rank * sz, lo + (self.rank + 1) * sz))
+        if self.tail is not None:
+            out.append(self.tail)
+        return out
+
+    def gather_params(self, flat_param: torch.Tensor):
+        """rs_ag: all-gather every parameter bucket from the ranks' updated shards (in place)."""
+        if not self.enabled or self.mode == "allreduce":
+            return
+        works = []
+        for lo, hi in reversed(self.buckets):
+            sz = (hi - lo) // self.world
+            buf = flat_param[lo:hi]
+            mine = buf[self.rank * sz:(self.rank + 1) * sz]
+            if self._gloo:
+                mine = mine.clone()
+                if self.max_inflight and len(works) >= self.max_inflight:
+                    works.pop(0).wait()
+            works.append(dist.all_gather_into_tensor(buf, mine, group=self.group, async_op=True))
+        for w in works:
+            w.wait()
+
+
+class _CopyAfter:
+    """wait() of an async work followed by a copy (gloo reduce-scatter through a temporary)."""
+
+    def __init__(self, work, src, dst):
+        self.work, self.src, self.dst = work, src, dst
+
+    def wait(self):
+        self.work.wait()
+        self.dst.copy_(self.src)
 
 
 @dataclass
@@ -104,11 +216,16 @@ class StepStats:
 
 
 class ForgetEngine:
-    """engine.step(micro_batches) = GA x (compute_loss -> backward) -> all-reduce -> clip -> AdamW -> zero grads."""
+    """engine.step(micro_batches) = GA x (compute_loss -> backward) -> gradient exchange -> clip -> AdamW -> zero grads.
+
+    dp_mode "allreduce" (default): bucketed SUM all-reduce overlapped with the last backward sweep, every rank runs the
+    full optimiser step.  dp_mode "rs_ag": reduce-scatter the buckets, each rank keeps optimiser state for and updates
+    only its 1/world shard of every bucket, then the updated parameter buckets are all-gathered (ZeRO-style; state
+    memory and AdamW traffic / world, same xGMI bytes as the all-reduce; the all-gather is not overlapped)."""
 
     def __init__(self, model, trainer, cfg: ForgetConfig, total_steps: int = 1000, warmup_steps: int = 0,
                  group=None, transposed_weights: bool = True, force_collectives: bool = False,
-                 optimizer: str = "adamw"):
+                 optimizer: str = "adamw", dp_mode: str = "allreduce", bucket_elems: int = 1 << 27):
         from . import hip  # HIP optimiser kernels; fails loudly when the library is missing
 
         self.hip = hip
@@ -118,11 +235,21 @@ class ForgetEngine:
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         dev = model.device
         self.grad = model.ensure_grad()
-        n = self.grad.numel()
+        self.reducer = GradBucketReducer(self.grad, group, bucket_elems=bucket_elems, force=force_collectives, mode=dp_mode)
+        self.dp_mode = dp_mode
+        # element ranges of the flat buffers this rank updates, and where each one's optimiser state starts
+        self.shards = self.reducer.shard_ranges()
+        self.shard_off = []
+        n = 0
+        for lo, hi in self.shards:
+            self.shard_off.append(n)
+            n += hi - lo
         # "adamw": fp32 moments (8 B/param).  "adamw8bit": block-wise 8-bit moments as in the reference's
         # optim="adamw_bnb_8bit" (mm/forget.py:156): 2 B/param + one fp32 absmax per 2048 parameters and moment.
         if optimizer not in ("adamw", "adamw8bit"):
             raise ValueError(f"unknown optimizer {optimizer}")
+        if optimizer == "adamw8bit" and len(self.shards) > 1:
+            raise ValueError("adamw8bit keeps block-wise state over the whole flat buffer: use dp_mode='allreduce'")
         self.optimizer = optimizer
         if optimizer == "adamw":
             self.m = torch.zeros(n, device=dev, dtype=torch.float32)
@@ -139,9 +266,28 @@ class ForgetEngine:
             self.am2 = torch.zeros(nb, device=dev, dtype=torch.float32)
         self.sumsq = torch.zeros(hip.SUMSQ_FLOATS, device=dev, dtype=torch.float32)  # [0] = |g|^2, rest scratch
         self.opt_step = 0
-        self.reducer = GradBucketReducer(self.grad, group, force=force_collectives)
+        # exposed gradient-exchange time: the stretch of the compute stream between the end of the last backward sweep
+        # and the completion of the last collective (device events; read by bench.py, never synchronised here)
+        self.time_exchange = False
+        self.exchange_events = []
         if transposed_weights:
             model.enable_transposed_weights()
+
+    def _grad_sumsq(self):
+        """|g|^2 over the whole (reduced) gradient into self.sumsq[0], identical on every rank."""
+        hip = self.hip
+        if len(self.shards) == 1:
+            hip.sumsq(self.grad, self.sumsq)
+            return
+        acc = torch.zeros(1, device=self.grad.device, dtype=torch.float32)
+        tail = self.reducer.tail
+        for lo, hi in self.shards:
+            if (lo, hi) == tail and self.reducer.rank != 0:
+                continue  # the replicated tail counts once
+            hip.sumsq(self.grad[lo:hi], self.sumsq)
+            acc += self.sumsq[0]
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=self.group)  # same bits on every rank
+        self.sumsq[0:1].copy_(acc)
 
     def step(self, micro_batches: List[Dict], sync_loss: bool = False) -> StepStats:
         ga = len(micro_batches)
@@ -149,26 +295,39 @@ class ForgetEngine:
         total = None
         for i, mb in enumerate(micro_batches):
             last = i == ga - 1
-            model.grad_ready_hook = self.reducer.reduce_range if (last and self.reducer.enabled) else None
+            model.grad_ready_hook = self.reducer.mark_final if (last and self.reducer.enabled) else None
             model.live_sweeps = 0
             loss = self.trainer.compute_loss(model, mb)
             (loss / ga).backward()
             d = loss.detach().float()
             total = d if total is None else total + d
         model.grad_ready_hook = None
+        ev = None
+        if self.time_exchange and self.reducer.enabled and self.grad.is_cuda:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         self.reducer.reduce_rest()
         self.reducer.wait()
-        self.opt_step += 1
-        lr = linear_schedule(self.opt_step, self.cfg.lr, self.warmup_steps, self.total_steps)
-        self.hip.sumsq(self.grad, self.sumsq)
+        if ev is not None:
+            ev[1].record()
+            self.exchange_events.append(ev)
+        lr = linear_schedule(self.opt_step, self.cfg.lr, self.warmup_steps, self.total_steps)  # lambda(k-1), as HF
+        self.opt_step += 1  # 1-based from here on: Adam bias correction of the k-th update
+        self._grad_sumsq()
+        c, p = self.cfg, model.train_flat.data
+        whole = len(self.shards) == 1
         if self.optimizer == "adamw":
-            self.hip.adamw(model.train_flat.data, self.grad, self.m, self.v, lr, self.cfg.adam_beta1, self.cfg.adam_beta2,
-                           self.cfg.adam_eps, self.cfg.weight_decay, self.opt_step, self.sumsq, self.cfg.max_grad_norm,
-                           1.0 / self.world, True)
+            for (lo, hi), off in zip(self.shards, self.shard_off):
+                self.hip.adamw(p[lo:hi], self.grad[lo:hi], self.m[off:off + hi - lo], self.v[off:off + hi - lo], lr,
+                               c.adam_beta1, c.adam_beta2, c.adam_eps, c.weight_decay, self.opt_step, self.sumsq,
+                               c.max_grad_norm, 1.0 / self.world, whole)
         else:
-            self.hip.adamw8bit(model.train_flat.data, self.grad, self.c1, self.c2, self.am1, self.am2, self.map1, self.map2,
-                               lr, self.cfg.adam_beta1, self.cfg.adam_beta2, self.cfg.adam_eps, self.cfg.weight_decay,
-                               self.opt_step, self.sumsq, self.cfg.max_grad_norm, 1.0 / self.world, True)
+            self.hip.adamw8bit(p, self.grad, self.c1, self.c2, self.am1, self.am2, self.map1, self.map2,
+                               lr, c.adam_beta1, c.adam_beta2, c.adam_eps, c.weight_decay,
+                               self.opt_step, self.sumsq, c.max_grad_norm, 1.0 / self.world, True)
+        if not whole:
+            self.grad.zero_()  # the other ranks' shards still hold this rank's unreduced partial sums
+            self.reducer.gather_params(p)
         model.refresh_derived()  # W^T copies (full fine-tuning) or LoRA's scaled / transposed adapter copies
         mean_loss = (total / ga)
         if sync_loss:
