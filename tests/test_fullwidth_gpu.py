@@ -1,0 +1,248 @@
+"""Full-WIDTH parity against the live fp32 oracle: LLaVA-1.5-7B and -13B widths (d 4096 / I 11008 /
+32 x 128 and d 5120 / I 13824 / 40 x 128, V 32064, CLIP-L/14-336 width cut to 2 layers, decoder cut to ONE layer),
+real-valued data, token counts large enough that every decoder Linear (forward, dgrad, wgrad) runs on the 256x256
+8-phase GEMM — the kernel the headline number is measured on — with each of its optional paths forced in turn:
+fused-RoPE epilogue, persistent launch, split-K tail, keep_act_t, transposed wgrad / TN wgrad, resident W^T dgrad.
+
+The oracle (oracle/llava_ref.py + oracle/forget_losses_ref.py, fp32, host cores) is run ONCE per (width, loss); every
+kernel configuration is compared against it:
+  logits  relative L2 < 1e-2 — or, where the reference's OWN bf16 path (the oracle run in bf16 = transformers' bf16
+          CPU arithmetic, every module output rounded) is itself further than that from fp32 on these inputs, no
+          further than 1.1x that distance (measured at 7B width, one layer, S 1088: HF-bf16 1.13e-2, HIP 1.04e-2)
+  loss    |d| < 1e-3 * max(1, |loss|)        every gradient tensor  relative L2 < 3e-2
+Reference arithmetic: /root/reference/mm/trainer.py:180-229,259-277 (`model(**inputs)`, grad_diff / KL branches) and,
+for the text trainer + LoRA case (BASELINE config 1), /root/reference/nlp/dataloader.py:144-200.
+"""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from multimodal_unlearning_amd.config import LlavaConfig, TextConfig, VisionConfig  # noqa: E402
+from multimodal_unlearning_amd.params import init_params  # noqa: E402
+from multimodal_unlearning_amd.synthetic import make_split, make_text_split, teacher_params_from  # noqa: E402
+
+KEYS = ("input_ids", "attention_mask", "pixel_values", "labels")
+
+
+def _cfg(width):
+    text = (TextConfig(num_layers=1) if width == "7b"
+            else TextConfig(hidden_size=5120, intermediate_size=13824, num_layers=1, num_heads=40))
+    return LlavaConfig(vision=VisionConfig(num_layers=3), text=text, name=f"fullwidth-{width}")
+
+
+def _relerr(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def _oracle(cfg, P, Pt, loss_type, inputs):
+    """fp32 loss, logits of the LAST student forward (retain) and gradients of every trainable tensor."""
+    from oracle.forget_losses_ref import compute_loss_ref
+    from oracle.llava_ref import llava_forward
+
+    torch.set_num_threads(16)
+    Pf = {k: v.clone().requires_grad_(not k.startswith("vision.")) for k, v in P.items()}
+    last = {}
+
+    def student(x):
+        out = llava_forward(cfg, Pf, **x)
+        last["logits"], last["inputs"] = out["logits"].detach(), x
+        return out
+
+    teacher = (lambda x: llava_forward(cfg, Pt, **x)) if Pt is not None else None
+    loss = compute_loss_ref(loss_type, student, teacher, inputs, 1.0)
+    loss.backward()
+    grads = {k: v.grad for k, v in Pf.items() if v.grad is not None}
+    # distance of the reference's own bf16 arithmetic from fp32 on the last student forward (the logits tolerance)
+    with torch.no_grad():
+        Pb = {k: v.detach().to(torch.bfloat16) for k, v in P.items()}
+        lb = llava_forward(cfg, Pb, **last["inputs"], dtype=torch.bfloat16)["logits"].float()
+    valid = last["inputs"]["attention_mask"].bool()
+    e_bf16 = _relerr(lb[valid], last["logits"][valid])
+    return float(loss.detach()), last["logits"], grads, e_bf16
+
+
+# kernel configurations: (name, dict of switches)
+CONFIGS = [
+    # the headline configuration: heuristic tiles, fused RoPE, persistent launch, heuristic tail split, W^T dgrad,
+    # transposed wgrad, act^T kept from the forward
+    ("default+keep_act_t", dict(keep_act_t=True, wt=True)),
+    # every GEMM forced onto the 256^2 kernel (CLIP and projector included), split-K tail whenever legal
+    ("tile256+tail2", dict(tile=256, tail=2, wt=True)),
+    # the alternatives: one workgroup per tile, no tail split, standalone RoPE kernel, TN wgrad, NN dgrad
+    ("nonpersistent+unfused", dict(persist=0, tail=0, fuse_rope=False, transposed_wgrad=False, wt=False)),
+]
+
+
+def _run_hip(dev, cfg, P, Pt, loss_type, inputs, sw, lora=None):
+    from multimodal_unlearning_amd import hip
+    from multimodal_unlearning_amd.llava import LlavaHIP
+    from multimodal_unlearning_amd.trainer import MMTrainerForgetting
+
+    hip.gemm_set_tile(sw.get("tile", 0))
+    hip.gemm_set_persistent(sw.get("persist", 1))
+    hip.gemm_set_tail_split(sw.get("tail", 1))
+    try:
+        model = LlavaHIP(cfg, P, device=dev)
+        model.fuse_rope = sw.get("fuse_rope", True)
+        model.transposed_wgrad = sw.get("transposed_wgrad", True)
+        model.keep_act_t = sw.get("keep_act_t", False)
+        if sw.get("wt", True):
+            model.enable_transposed_weights()
+        teacher = LlavaHIP(cfg, Pt, device=dev, trainable=False) if Pt is not None else None
+        tr = MMTrainerForgetting(model=model, forget_loss=loss_type, teacher_model=teacher, loss_beta=1.0, l1_lambda=0.0,
+                                 l0_lambda=0.0, l_norm_from="zero", loss_args={})
+        model.ensure_grad().zero_()
+        loss, out = tr.compute_loss(model, inputs, return_outputs=True)
+        loss.backward()
+        torch.cuda.synchronize()
+        grads = {k: v.detach().float().cpu() for k, v in model.g.items()}
+        return float(loss), out.logits.detach().float().cpu(), grads
+    finally:
+        hip.gemm_set_tile(0)
+        hip.gemm_set_persistent(1)
+        hip.gemm_set_tail_split(1)
+
+
+def _check(tag, got, ref):
+    loss, logits, grads = got
+    rloss, rlogits, rgrads, e_bf16 = ref
+    assert abs(loss - rloss) < 1e-3 * max(1.0, abs(rloss)), (tag, loss, rloss)
+    el = _relerr(logits.reshape(rlogits.shape), rlogits)
+    assert el < max(1e-2, 1.1 * e_bf16), (tag, "logits", el, "HF-bf16 path", e_bf16)
+    worst = ("", 0.0)
+    for k, rg in rgrads.items():
+        e = _relerr(grads[k], rg)
+        if e > worst[1]:
+            worst = (k, e)
+        assert e < 3e-2, (tag, k, e)
+    return worst + (el, e_bf16)
+
+
+@pytest.mark.parametrize("width", ["7b", "13b"])
+def test_grad_diff_full_width_vs_oracle(dev, width):
+    """grad_diff_forget_ce_retain_ce (the headline loss), paired fusion: ONE forward/backward over cat(forget, retain) =
+    2 sequences x S 1088 = 2176 tokens (8.5 tile rows: M tail, persistent launch on qkv / gate_up / lm_head)."""
+    from multimodal_unlearning_amd import hip
+
+    cfg = _cfg(width)
+    t = cfg.text
+    S = cfg.vision.num_patches + 512
+    M = 2 * S
+    for (n, k) in ((3 * t.hidden_size, t.hidden_size), (t.hidden_size, t.hidden_size), (2 * t.intermediate_size, t.hidden_size),
+                   (t.hidden_size, t.intermediate_size), (t.vocab_size, t.hidden_size)):
+        assert hip.load().mmu_gemm_uses_256(M, n, k), (M, n, k)      # forward y = x W^T
+        assert hip.load().mmu_gemm_uses_256(M, k, n), (M, k, n)      # dgrad dx = dy W
+        assert hip.load().mmu_gemm_uses_256(n, k, M), (n, k, M)      # wgrad dW = dy^T x
+    P = init_params(cfg, seed=11)
+    inputs = {"forget": make_split(cfg, 1, S, seed=501, n_question=S - 1 - cfg.vision.num_patches - 256),
+              "retain": make_split(cfg, 1, S, seed=502, n_question=S - 1 - cfg.vision.num_patches - 200)}
+    # the oracle's `last logits` are the retain forward's: the fused HIP forward returns cat(forget, retain)
+    ref = _oracle(cfg, P, None, "grad_diff_forget_ce_retain_ce", inputs)
+    for name, sw in CONFIGS:
+        loss, logits, grads = _run_hip(dev, cfg, P, None, "grad_diff_forget_ce_retain_ce", inputs, sw)
+        w = _check(f"{width}/{name}", (loss, logits[1:2], grads), ref)
+        print(f"[fullwidth {width} grad_diff {name}] loss {loss:+.5f} vs {ref[0]:+.5f}; logits {w[2]:.2e} (HF-bf16 {w[3]:.2e}); "
+              f"worst grad {w[0]} {w[1]:.2e}")
+
+
+@pytest.mark.parametrize("width", ["7b", "13b"])
+def test_kl_full_width_vs_oracle(dev, width):
+    """KL (mm/trainer.py:259-277): -CE(forget) + KL(student_retain || teacher_retain) with a frozen full-width
+    teacher; two student sweeps in one backward; 3 sequences x S 704 per split with LEFT padding on two rows."""
+    cfg = _cfg(width)
+    S, B = cfg.vision.num_patches + 128, 3
+    P = init_params(cfg, seed=12)
+    Pt = teacher_params_from(P, seed=7)
+    inputs = {"forget": make_split(cfg, B, S, seed=601, n_question=40, left_pad=[0, 37, 5]),
+              "retain": make_split(cfg, B, S, seed=602, n_question=30, left_pad=[11, 0, 0])}
+    ref = _oracle(cfg, P, Pt, "KL", inputs)
+    valid = inputs["retain"]["attention_mask"].bool()
+    for name, sw in CONFIGS[:2]:
+        loss, logits, grads = _run_hip(dev, cfg, P, Pt, "KL", inputs, sw)
+        # padded positions hold unspecified logits on both sides (HF gives them finite garbage too): compare valid rows
+        w = _check(f"{width}/{name}", (loss, logits[valid], grads), (ref[0], ref[1][valid], ref[2], ref[3]))
+        print(f"[fullwidth {width} KL {name}] loss {loss:+.5f} vs {ref[0]:+.5f}; logits {w[2]:.2e} (HF-bf16 {w[3]:.2e}); "
+              f"worst grad {w[0]} {w[1]:.2e}")
+
+
+def test_nlp_tuple_trainer_lora_r8_full_width_vs_oracle(dev):
+    """BASELINE config 1's workload: the text trainer (tuple inputs [B,500] right-padded, nlp/dataloader.py:144-200,
+    nlp/data_module.py:10-43) with LoRA r=8 alpha=32 on every decoder Linear + lm_head, grad_ascent, at Llama-2-7B
+    width (one layer).  peft is not importable: the adapter arithmetic is pinned to y = W x + (alpha/r) B A x through
+    the fp32 oracle on W + (alpha/r) B A with the adapters as autograd leaves (parity unpinned vs peft itself)."""
+    from multimodal_unlearning_amd.llava import LlavaHIP, LoraSpec
+    from multimodal_unlearning_amd.trainer import CustomTrainerForgetting
+    from oracle.forget_losses_ref import compute_loss_ref
+    from oracle.llava_ref import llava_forward
+
+    cfg = _cfg("7b")
+    S, B = 500, 5  # 2500 tokens per forward
+    P = init_params(cfg, seed=13)
+    spec = LoraSpec(r=8, alpha=32.0, targets=("qkv", "o", "gate_up", "down", "lm_head"))
+    model = LlavaHIP(cfg, P, device=dev, lora=spec)
+    model.init_lora_(seed=3, b_std=0.02)
+    model.enable_transposed_weights()
+    sp = [make_text_split(cfg, B, S, seed=700 + j, n_question=S // 4, right_pad=[(7 * b) % 90 for b in range(B)])
+          for j in range(2)]
+    tup = [(s["input_ids"], s["labels"], s["attention_mask"]) for s in sp]
+    tr = CustomTrainerForgetting(model=model, forget_loss="grad_ascent", oracle_model=None, loss_beta=1.0, l1_lambda=0.0,
+                                 l0_lambda=0.0)
+    model.ensure_grad().zero_()
+    loss = tr.compute_loss(model, tup)
+    loss.backward()
+    torch.cuda.synchronize()
+    torch.set_num_threads(16)
+    leaves = {}
+    Pe = {k: v.clone() for k, v in P.items()}
+    for wname, ad in model.lora.items():
+        A = ad.A32.detach().float().cpu().requires_grad_(True)
+        Bm = ad.BL.detach().float().cpu().requires_grad_(True)
+        leaves[wname] = (A, Bm, ad.mask.float().cpu())
+        Pe[wname] = P[wname] + spec.scaling * (Bm @ A)
+    nested = {"forget": {k: v for k, v in sp[0].items()}, "retain": {k: v for k, v in sp[1].items()}}
+    ref = compute_loss_ref("grad_ascent", lambda x: llava_forward(cfg, Pe, **x), None, nested, 1.0)
+    ref.backward()
+    assert abs(loss.item() - ref.item()) < 1e-3 * max(1.0, abs(ref.item())), (loss.item(), ref.item())
+    for wname, (A, Bm, mask) in leaves.items():
+        base = wname[: -len(".weight")]
+        eA = _relerr(model.g[base + ".lora_A"], A.grad)
+        eB = _relerr(model.g[base + ".lora_B"], Bm.grad * mask)
+        assert eA < 3e-2 and eB < 3e-2, (wname, eA, eB)
+    print(f"[fullwidth nlp LoRA r8] loss {loss.item():+.5f} vs {ref.item():+.5f}")
+
+
+def test_hf_full_width_golden_slice(dev):
+    """SURVEY §8(c) golden slice: ONE full-width decoder layer (d 4096, V 32064, S 128, text only) computed by the
+    transformers LlamaForCausalLM installed in the build container (oracle/make_golden_fullwidth.py); the weights are
+    re-generated from the seed, the golden holds inputs, loss, logits at 8 rows and gradient norms."""
+    import os
+
+    import numpy as np
+
+    from multimodal_unlearning_amd.llava import LlavaHIP
+
+    path = os.path.join(os.path.dirname(__file__), "golden", "llama_fullwidth_hf.npz")
+    g = np.load(path)
+    cfg = _cfg("7b")
+    P = init_params(cfg, seed=int(g["seed"]))
+    model = LlavaHIP(cfg, P, device=dev)
+    model.enable_transposed_weights()
+    ids = torch.from_numpy(g["input_ids"])
+    labels = torch.from_numpy(g["labels"])
+    model.ensure_grad().zero_()
+    out = model(input_ids=ids, attention_mask=torch.ones_like(ids), labels=labels)
+    out.loss.backward()
+    torch.cuda.synchronize()
+    ref_loss = float(g["loss"])
+    assert abs(out.loss.item() - ref_loss) < 1e-3 * max(1.0, abs(ref_loss)), (out.loss.item(), ref_loss)
+    rows = g["logit_rows"]  # [n, 2] (b, s)
+    got = torch.stack([out.logits[int(b), int(s)].float().cpu() for b, s in rows])
+    assert _relerr(got, torch.from_numpy(g["logits_at_rows"])) < 1e-2
+    for k in [n for n in g.files if n.startswith("gradnorm.")]:
+        name = k[len("gradnorm."):]
+        gn, rn = model.g[name].float().norm().item(), float(g[k])
+        assert abs(gn - rn) < 2e-2 * rn, (name, gn, rn)
