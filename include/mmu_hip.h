@@ -157,6 +157,40 @@ int mmu_rowloss_fwd(int mode, const void* slog, const void* tlog, int ldv, float
 int mmu_rowloss_bwd(int mode, const void* slog, const void* tlog, int ldv, float beta, const float* stats,
                     const float* coef, void* dlogits, int ldd, int M, int V, void* stream);
 
+/* remove_image_tokens (mm/trainer_utils.py:48-70): dst[r][:] = src[rows[r]][:] for n_dst_rows rows of V bf16 (V % 8 == 0);
+ * rows: device int64, flat source row indices computed on the device by the caller (no host loop, no sync). */
+int mmu_gather_rows_bf16(const void* src, const long long* rows, void* dst, long long n_src_rows, int n_dst_rows, int V,
+                         void* stream);
+
+/* Evaluation truth-ratio pass (mm/eval.py:46-92 eval_perturbation_ratio: get_batch_loss + token counts) for n_seq
+ * sequences of S rows in one call: out[seq] = {sum_t shifted CE, #shifted targets != -100, #labels != -100 (unshifted:
+ * the normaliser of mm/eval.py:70-71)}.  lse_scratch / row_scratch: n_seq * S floats each. */
+int mmu_seq_ce_stats(const void* logits, int ldv, const long long* labels, int n_seq, int S, int V, float* lse_scratch,
+                     float* row_scratch, float* out, void* stream);
+
+/* 1 forces the streaming row-loss kernel (student / teacher rows walked twice); default 0: rows of V <= 32768 logits are
+ * held in registers and cross HBM once (same arithmetic, different summation order).  A/B and test switch. */
+int mmu_rowloss_set_streaming(int on);
+
+/* ---- RMU terms (mm/trainer.py:302-326: mse_loss(mean_seq(act_f), control) * beta + mse_loss(act_r, act_r_teacher);
+ * nlp/dataloader.py:339-367: mse_loss(act_f, control broadcast)) on the captured decoder-layer activation
+ * [B, S, H] bf16.  Deterministic two-stage reductions; `out` buffers hold 1 + mmu_red_scratch_floats() floats, the
+ * result in slot 0.
+ *   mmu_mse_fwd       out[0] = sum_i (a_i - ref_i)^2, ref = b_i (bf16 [n]) or, when b == NULL, cvec[i % H] (fp32 [H])
+ *   mmu_mse_bwd       da_i = *coef * (a_i - ref_i)            (the caller folds 2 / n and the upstream gradient into coef)
+ *   mmu_seqmean_fwd   mean[b,h] = (1/S) sum_s a[b,s,h];  partial = mmu_seqmean_nsplit(S) * B * H floats of scratch
+ *   mmu_rmu_pair_fwd  out[0] = sum_{i<B, j<Bc, h} (mean[i,h] - ctrl[j,h])^2   ([B,H] vs [Bc,1,H] broadcasts to [Bc,B,H])
+ *   mmu_rmu_pair_bwd  da[i,s,h] = *coef / S * sum_j (mean[i,h] - ctrl[j,h])   (bf16 [B,S,H]) */
+int mmu_red_scratch_floats(void);
+int mmu_mse_fwd(const void* a, const void* b, const float* cvec, long long n, int H, float* out, void* stream);
+int mmu_mse_bwd(const void* a, const void* b, const float* cvec, long long n, int H, const float* coef, void* da,
+                void* stream);
+int mmu_seqmean_nsplit(int S);
+int mmu_seqmean_fwd(const void* a, int B, int S, int H, float* partial, float* mean, void* stream);
+int mmu_rmu_pair_fwd(const float* mean, const float* ctrl, int B, int Bc, int H, float* out, void* stream);
+int mmu_rmu_pair_bwd(const float* mean, const float* ctrl, int B, int Bc, int S, int H, const float* coef, void* da,
+                     void* stream);
+
 /* ---- L1 / L0 regulariser of compute_loss (mm/trainer.py:451-481: torch.norm(cat(param - teacher_param), p=1 | 0)) over
  * the flat trainable buffer: d = bf16(p - t) (t = NULL: d = p); out2[0] += sum|d|, out2[1] += #(d != 0) in fp64.
  * Backward: g += lambda1 * *gout * sign(d) (gout: device scalar = upstream gradient, NULL = 1; L0 has no gradient). */
@@ -168,9 +202,11 @@ int mmu_l1_bwd(const void* p, const void* t, long long n, void* g, float lambda1
  * the same all-reduced gradient); out_sumsq needs 1 + mmu_sumsq_scratch_floats() floats (partials after slot 0). */
 int mmu_sumsq_bf16(const void* g, long long n, float* out_sumsq, void* stream);
 int mmu_sumsq_scratch_floats(void);
+/* nodecay: device array of n_nodecay (<= 512) sorted, disjoint element ranges [lo, hi) of p (multiples of 8) that get no
+ * weight decay — transformers.Trainer.create_optimizer decays neither biases nor norm weights — or NULL / 0. */
 int mmu_adamw_bf16(void* p, void* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
                    float weight_decay, int step, const float* sumsq, float max_norm, float grad_scale, int zero_grad,
-                   void* stream);
+                   const long long* nodecay, int n_nodecay, void* stream);
 /* AdamW with block-wise 8-bit moments (the reference's optim="adamw_bnb_8bit", mm/forget.py:156; bitsandbytes is not in
  * /root/reference: published algorithm restated, parity unpinned): blocks of 2048 parameters, 8-bit codes of a
  * 256-entry dynamic quantisation map (map1 signed for m, map2 unsigned for v; device pointers) times an fp32 absmax
@@ -179,7 +215,8 @@ int mmu_adamw_bf16(void* p, void* g, float* m, float* v, long long n, float lr, 
 int mmu_adamw8bit_nblocks(long long n);
 int mmu_adamw8bit_bf16(void* p, void* g, void* codes1, void* codes2, float* absmax1, float* absmax2, const float* map1,
                        const float* map2, long long n, float lr, float beta1, float beta2, float eps, float weight_decay,
-                       int step, const float* sumsq, float max_norm, float grad_scale, int zero_grad, void* stream);
+                       int step, const float* sumsq, float max_norm, float grad_scale, int zero_grad,
+                       const long long* nodecay, int n_nodecay, void* stream);
 int mmu_scale_bf16(void* x, long long n, float s, void* stream);
 
 #ifdef __cplusplus

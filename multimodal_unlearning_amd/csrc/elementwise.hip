@@ -1073,3 +1073,26 @@ extern "C" int mmu_swiglu_bwd_t(const void* gu, const void* dh, void* dgu, void*
     MMU_CHECK_LAUNCH();
     return 0;
 }
+
+// remove_image_tokens (mm/trainer_utils.py:48-70) without the reference's host loop: the caller computes, on the
+// device, the source row of every kept logits row (first `start` rows and last T - start rows of each sequence); this
+// kernel copies the selected rows.  dst[r][:] = src[rows[r]][:], one workgroup per destination row, 16-B moves.
+namespace {
+__global__ __launch_bounds__(256) void gather_rows_kernel(const bf16* __restrict__ src, const long long* __restrict__ rows,
+                                                          bf16* __restrict__ dst, int V8, long long n_src_rows) {
+    const long long r = rows[blockIdx.x];
+    if (r < 0 || r >= n_src_rows) return;  // never true for indices built by remove_image_tokens; keeps a bad index in bounds
+    const bf16* s = src + (size_t)r * V8 * 8;
+    bf16* d = dst + (size_t)blockIdx.x * V8 * 8;
+    for (int c = threadIdx.x; c < V8; c += 256) *reinterpret_cast<bf16x8*>(d + c * 8) = *reinterpret_cast<const bf16x8*>(s + c * 8);
+}
+}  // namespace
+extern "C" int mmu_gather_rows_bf16(const void* src, const long long* rows, void* dst, long long n_src_rows, int n_dst_rows,
+                                    int V, void* stream) {
+    if (n_src_rows <= 0 || n_dst_rows <= 0 || V <= 0 || (V & 7) || !rows) return -1;
+    if (((uintptr_t)src | (uintptr_t)dst) & 15) return -1;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(n_dst_rows), dim3(256), 0, (hipStream_t)stream, (const bf16*)src, rows,
+                       (bf16*)dst, V >> 3, n_src_rows);
+    MMU_CHECK_LAUNCH();
+    return 0;
+}

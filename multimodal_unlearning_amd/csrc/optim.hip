@@ -81,7 +81,22 @@ __global__ __launch_bounds__(256) void l1_bwd_kernel(const bf16* __restrict__ p,
     }
 }
 
+// Element ranges [lo, hi) of p (multiples of 8, sorted, disjoint) that get NO weight decay: transformers.Trainer puts
+// biases and norm weights in a weight_decay = 0 group (create_optimizer / get_decay_parameter_names), which is the loop
+// the reference trains under (mm/forget.py:139-190).  The table is staged in LDS and searched once per 8-element group.
+constexpr int MAX_NODECAY = 512;
+__device__ __forceinline__ bool in_nodecay(const long long* __restrict__ nd, int n, long long e) {
+    int lo = 0, hi = n;  // first range with start > e
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (nd[2 * mid] <= e) lo = mid + 1; else hi = mid;
+    }
+    return lo > 0 && e < nd[2 * lo - 1];
+}
+
 struct AdamArgs {
+    const long long* nodecay;
+    int n_nodecay;
     bf16* p;
     bf16* g;
     float* m;
@@ -95,14 +110,18 @@ struct AdamArgs {
 };
 
 __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
+    __shared__ long long nd[2 * MAX_NODECAY];
+    for (int i = threadIdx.x; i < 2 * a.n_nodecay; i += 256) nd[i] = a.nodecay[i];
+    if (a.n_nodecay) __syncthreads();
     float gs = a.grad_scale;
     if (a.sumsq && a.max_norm > 0.f) {
         const float tn = sqrtf(*a.sumsq) * a.grad_scale;
         gs *= fminf(1.f, a.max_norm / (tn + 1e-6f));
     }
     const float step = a.lr / a.bc1;
-    const float decay = 1.f - a.lr * a.wd;
+    const float decay_on = 1.f - a.lr * a.wd;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n8; i += (size_t)gridDim.x * blockDim.x) {
+        const float decay = (a.n_nodecay && in_nodecay(nd, a.n_nodecay, (long long)(i * 8))) ? 1.f : decay_on;
         const bf16x8 pv = *reinterpret_cast<const bf16x8*>(a.p + i * 8);
         const bf16x8 gv = *reinterpret_cast<const bf16x8*>(a.g + i * 8);
         f32x4 m0 = *reinterpret_cast<const f32x4*>(a.m + i * 8), m1 = *reinterpret_cast<const f32x4*>(a.m + i * 8 + 4);
@@ -142,6 +161,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
 // the bf16 parameters, requantise to the nearest code.  10 B/param of HBM traffic instead of 24.
 constexpr int Q8_BLOCK = 2048;
 struct Adam8Args {
+    const long long* nodecay;
+    int n_nodecay;
     bf16* p;
     bf16* g;
     unsigned char* c1;
@@ -173,6 +194,8 @@ __device__ __forceinline__ int q8_nearest(const float* __restrict__ map, float x
 __global__ __launch_bounds__(256) void adamw8bit_kernel(Adam8Args a) {
     __shared__ float m1s[256], m2s[256];
     __shared__ float red[2][4];
+    __shared__ long long nd[2 * MAX_NODECAY];
+    for (int i = threadIdx.x; i < 2 * a.n_nodecay; i += 256) nd[i] = a.nodecay[i];
     m1s[threadIdx.x] = a.map1[threadIdx.x];
     m2s[threadIdx.x] = a.map2[threadIdx.x];
     float gs = a.grad_scale;
@@ -181,7 +204,6 @@ __global__ __launch_bounds__(256) void adamw8bit_kernel(Adam8Args a) {
         gs *= fminf(1.f, a.max_norm / (tn + 1e-6f));
     }
     const float step = a.lr / a.bc1;
-    const float decay = 1.f - a.lr * a.wd;
     const size_t blk = blockIdx.x;
     const size_t i0 = blk * Q8_BLOCK + (size_t)threadIdx.x * 8;
     const bool live = i0 < a.n;  // n % 8 == 0: a thread's 8 elements are all in or all out
@@ -214,6 +236,7 @@ __global__ __launch_bounds__(256) void adamw8bit_kernel(Adam8Args a) {
     if (threadIdx.x == 0) { a.am1[blk] = nm1; a.am2[blk] = nm2; }
     if (!live) return;
     const float r1 = nm1 > 0.f ? 1.f / nm1 : 0.f, r2 = nm2 > 0.f ? 1.f / nm2 : 0.f;
+    const float decay = (a.n_nodecay && in_nodecay(nd, a.n_nodecay, (long long)i0)) ? 1.f : 1.f - a.lr * a.wd;
     bf16x8 po;
     unsigned long long o1 = 0, o2 = 0;
 #pragma unroll
@@ -286,9 +309,10 @@ extern "C" int mmu_l1_bwd(const void* p, const void* t, long long n, void* g, fl
 
 extern "C" int mmu_adamw_bf16(void* p, void* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
                               float eps, float weight_decay, int step, const float* sumsq, float max_norm,
-                              float grad_scale, int zero_grad, void* stream) {
-    if (n <= 0 || (n & 7) || step < 1) return -1;
+                              float grad_scale, int zero_grad, const long long* nodecay, int n_nodecay, void* stream) {
+    if (n <= 0 || (n & 7) || step < 1 || n_nodecay < 0 || n_nodecay > MAX_NODECAY || (n_nodecay && !nodecay)) return -1;
     AdamArgs a;
+    a.nodecay = nodecay; a.n_nodecay = n_nodecay;
     a.p = (bf16*)p; a.g = (bf16*)g; a.m = m; a.v = v; a.n8 = (size_t)n / 8;
     a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = weight_decay;
     a.bc1 = 1.f - powf(beta1, (float)step);
@@ -307,10 +331,12 @@ extern "C" int mmu_adamw8bit_nblocks(long long n) { return (int)((n + Q8_BLOCK -
 extern "C" int mmu_adamw8bit_bf16(void* p, void* g, void* codes1, void* codes2, float* absmax1, float* absmax2,
                                   const float* map1, const float* map2, long long n, float lr, float beta1, float beta2,
                                   float eps, float weight_decay, int step, const float* sumsq, float max_norm,
-                                  float grad_scale, int zero_grad, void* stream) {
+                                  float grad_scale, int zero_grad, const long long* nodecay, int n_nodecay, void* stream) {
+    if (n_nodecay < 0 || n_nodecay > MAX_NODECAY || (n_nodecay && !nodecay)) return -1;
     if (n <= 0 || (n & 7) || step < 1 || !codes1 || !codes2 || !absmax1 || !absmax2 || !map1 || !map2) return -1;
     if (((uintptr_t)codes1 | (uintptr_t)codes2) & 7) return -1;
     Adam8Args a;
+    a.nodecay = nodecay; a.n_nodecay = n_nodecay;
     a.p = (bf16*)p; a.g = (bf16*)g; a.c1 = (unsigned char*)codes1; a.c2 = (unsigned char*)codes2;
     a.am1 = absmax1; a.am2 = absmax2; a.map1 = map1; a.map2 = map2; a.n = (size_t)n;
     a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = weight_decay;
@@ -332,4 +358,4 @@ extern "C" int mmu_scale_bf16(void* x, long long n, float s, void* stream) {
     return 0;
 }
 
-extern "C" int mmu_abi_version(void) { return 1; }
+extern "C" int mmu_abi_version(void) { return 2; }

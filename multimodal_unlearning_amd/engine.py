@@ -264,6 +264,14 @@ class ForgetEngine:
             nb = hip.adamw8bit_nblocks(n)
             self.am1 = torch.zeros(nb, device=dev, dtype=torch.float32)
             self.am2 = torch.zeros(nb, device=dev, dtype=torch.float32)
+        # transformers.Trainer.create_optimizer decays neither biases nor norm weights: per shard, the element ranges
+        # (relative to the shard) that the AdamW kernel must not decay
+        from .params import no_weight_decay
+        nd_abs = sorted(model.range_of(n) for n in model.trainable_names() if no_weight_decay(n))
+        self.nodecay = []
+        for lo, hi in self.shards:
+            rel = [(max(a, lo) - lo, min(b, hi) - lo) for a, b in nd_abs if a < hi and lo < b]
+            self.nodecay.append(torch.tensor(rel, device=dev, dtype=torch.int64).reshape(-1, 2) if rel else None)
         self.sumsq = torch.zeros(hip.SUMSQ_FLOATS, device=dev, dtype=torch.float32)  # [0] = |g|^2, rest scratch
         self.opt_step = 0
         # exposed gradient-exchange time: the stretch of the compute stream between the end of the last backward sweep
@@ -317,14 +325,14 @@ class ForgetEngine:
         c, p = self.cfg, model.train_flat.data
         whole = len(self.shards) == 1
         if self.optimizer == "adamw":
-            for (lo, hi), off in zip(self.shards, self.shard_off):
+            for (lo, hi), off, nd in zip(self.shards, self.shard_off, self.nodecay):
                 self.hip.adamw(p[lo:hi], self.grad[lo:hi], self.m[off:off + hi - lo], self.v[off:off + hi - lo], lr,
                                c.adam_beta1, c.adam_beta2, c.adam_eps, c.weight_decay, self.opt_step, self.sumsq,
-                               c.max_grad_norm, 1.0 / self.world, whole)
+                               c.max_grad_norm, 1.0 / self.world, whole, nodecay=nd)
         else:
             self.hip.adamw8bit(p, self.grad, self.c1, self.c2, self.am1, self.am2, self.map1, self.map2,
                                lr, c.adam_beta1, c.adam_beta2, c.adam_eps, c.weight_decay,
-                               self.opt_step, self.sumsq, c.max_grad_norm, 1.0 / self.world, True)
+                               self.opt_step, self.sumsq, c.max_grad_norm, 1.0 / self.world, True, nodecay=self.nodecay[0])
         if not whole:
             self.grad.zero_()  # the other ranks' shards still hold this rank's unreduced partial sums
             self.reducer.gather_params(p)

@@ -1,48 +1,77 @@
-"""Evaluation truth-ratio pass on the HIP model: host-side mirror of mm/eval.py:46-92 `eval_perturbation_ratio`
-(same log keys, same arithmetic: per-sequence CE sums via get_batch_loss, per-token normalisation by the count of
-non-ignored UNSHIFTED labels, truth_ratio = exp(gt/tok - mean_k perturb/tok)).  Its output feeds
-metrics.evaluate_forget_quality (the `eval_log_forget.json` section of eval_log_aggregated.json)."""
+"""Evaluation truth-ratio pass on the HIP model.
+
+Produces the `eval_log_forget.json` section of `eval_log_aggregated.json` that mm/eval.py:46-92
+(`eval_perturbation_ratio`) writes and mm/calculate_metrics.py:51-72 reads: per sample index, the ground-truth /
+paraphrased answer's CE (sum and per token), the K perturbed answers' CE (sum and per token) and
+truth_ratio = exp(gt per token - mean_k perturbed per token).  Same keys, same normalisers (token counts are the
+number of labels != -100 of the UNSHIFTED row), same values.
+
+MI355X shape of the pass: every sequence of a batch — the B ground-truth rows and the B*K perturbed rows — goes through
+ONE forward each way and ONE C-ABI call (`mmu_seq_ce_stats`: fused row log-sum-exp + target gather, then a per-sequence
+reduction returning {CE sum, shifted-target count, label count}); the statistics of all batches stay on the device and
+the ratios are formed there; a single device->host copy at the end fills the log dictionaries.
+"""
 from __future__ import annotations
 
-from collections import defaultdict
+from collections import OrderedDict
+from typing import Dict, Iterable
 
 import torch
 
+from . import hip
 from . import trainer_utils as tu
 
+LOG_KEYS = ("average_perturb_loss", "avg_paraphrased_loss", "truth_ratio", "paraphrased_loss", "perturb_loss",
+            "num_token_paraphrased", "num_token_perturb")
 
-def eval_perturbation_ratio(eval_dataloader, perturb_dataloader, model):
-    eval_logs = defaultdict(dict)
+
+def sequence_ce_stats(model, split: Dict[str, torch.Tensor]) -> torch.Tensor:
+    """float32 [n, 3] on the device: per sequence {sum_t CE, #shifted targets != -100, #labels != -100}."""
     dev = next(model.parameters()).device
-    image_token_id = model.config.image_token_index
+    split = {k: v.to(dev) for k, v in split.items()}
+    with torch.no_grad():
+        logits = model(**{k: v for k, v in split.items() if k != "labels"}).logits
+    logits = tu.remove_image_tokens(split["input_ids"], logits, model.config.image_token_index)
+    return hip.seq_ce_stats(logits.contiguous(), split["labels"].to(torch.int64).contiguous())
+
+
+def _flatten_perturbed(pb: Dict[str, torch.Tensor]):
+    """[B, K, ...] token tensors -> [B*K, ...]; pixel_values arrive already flat ([B*K, 3, H, W]) or as [B, K, 3, H, W]."""
+    B, K = pb["input_ids"].shape[:2]
+    out = {}
+    for k, v in pb.items():
+        if k == "pixel_values":
+            out[k] = v.reshape(-1, *v.shape[-3:])
+        else:
+            out[k] = v.reshape(B * K, *v.shape[2:])
+    return out, B, K
+
+
+def eval_perturbation_ratio(eval_dataloader: Iterable, perturb_dataloader: Iterable, model) -> "OrderedDict[str, dict]":
+    idx_all, gt_all, pt_all = [], [], []
     for batch, perturb_batch in zip(eval_dataloader, perturb_dataloader):
         batch, perturb_batch = dict(batch), dict(perturb_batch)
-        indices = batch.pop("indices")
-        perturb_batch.pop("indices")
-        bsz, num_seq = perturb_batch["input_ids"].shape[0:2]
-        for k, v in perturb_batch.items():
-            if v.shape[:2] == (bsz, num_seq):
-                perturb_batch[k] = v.reshape(bsz * num_seq, *v.shape[2:]) if k == "pixel_values" else v.reshape(bsz * num_seq, -1)
-        batch = {k: v.to(dev) for k, v in batch.items()}
-        perturb_batch = {k: v.to(dev) for k, v in perturb_batch.items()}
-        with torch.no_grad():
-            outputs = model(**batch)
-            perturb_outputs = model(**perturb_batch)
-            out_logits = tu.remove_image_tokens(batch["input_ids"], outputs.logits, image_token_id)
-            gt_loss = tu.get_batch_loss(out_logits, batch["labels"])
-            pl = tu.remove_image_tokens(perturb_batch["input_ids"], perturb_outputs.logits, image_token_id)
-            perturb_loss = tu.get_batch_loss(pl, perturb_batch["labels"]).view(bsz, num_seq)
-        num_token_gt = (batch["labels"] != -100).sum(-1)
-        num_token_perturb = (perturb_batch["labels"] != -100).view(bsz, num_seq, -1).sum(-1)
-        perturb_loss_per_token = perturb_loss / num_token_perturb
-        gt_loss_per_token = gt_loss / num_token_gt
-        truth_ratio = torch.exp(gt_loss_per_token - perturb_loss_per_token.mean(-1))
-        idx_list = indices.tolist()
-        eval_logs["average_perturb_loss"].update(dict(zip(idx_list, perturb_loss_per_token.tolist())))
-        eval_logs["avg_paraphrased_loss"].update(dict(zip(idx_list, gt_loss_per_token.tolist())))
-        eval_logs["truth_ratio"].update(dict(zip(idx_list, truth_ratio.tolist())))
-        eval_logs["paraphrased_loss"].update(dict(zip(idx_list, gt_loss.tolist())))
-        eval_logs["perturb_loss"].update(dict(zip(idx_list, perturb_loss.tolist())))
-        eval_logs["num_token_paraphrased"].update(dict(zip(idx_list, num_token_gt.tolist())))
-        eval_logs["num_token_perturb"].update(dict(zip(idx_list, num_token_perturb.tolist())))
-    return eval_logs
+        idx_all.append(batch.pop("indices").reshape(-1).to(torch.int64).cpu())
+        perturb_batch.pop("indices", None)
+        flat, B, K = _flatten_perturbed(perturb_batch)
+        gt_all.append(sequence_ce_stats(model, batch))                   # [B, 3]
+        pt_all.append(sequence_ce_stats(model, flat).view(B, K, 3))      # [B, K, 3]
+    logs: "OrderedDict[str, dict]" = OrderedDict((k, {}) for k in LOG_KEYS)
+    if not idx_all:
+        return logs
+    gt, pt = torch.cat(gt_all), torch.cat(pt_all)
+    gt_per_tok = gt[:, 0] / gt[:, 2]
+    pt_per_tok = pt[..., 0] / pt[..., 2]
+    truth_ratio = torch.exp(gt_per_tok - pt_per_tok.mean(-1))
+    # one copy to the host for everything the log holds
+    host = torch.cat([gt[:, 0:1], gt[:, 2:3], gt_per_tok[:, None], truth_ratio[:, None], pt[..., 0], pt[..., 2],
+                      pt_per_tok], dim=1).cpu()
+    K = pt.shape[1]
+    cols = {"paraphrased_loss": host[:, 0], "num_token_paraphrased": host[:, 1].round().to(torch.int64),
+            "avg_paraphrased_loss": host[:, 2], "truth_ratio": host[:, 3], "perturb_loss": host[:, 4:4 + K],
+            "num_token_perturb": host[:, 4 + K:4 + 2 * K].round().to(torch.int64),
+            "average_perturb_loss": host[:, 4 + 2 * K:4 + 3 * K]}
+    index = torch.cat(idx_all).tolist()
+    for key, col in cols.items():
+        logs[key] = dict(zip(index, col.tolist()))
+    return logs

@@ -69,13 +69,24 @@ SIGNATURES = {
     "mmu_seg_reduce": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp],
     "mmu_rowloss_fwd": [_i, _vp, _vp, _i, _f, _vp, _i, _i, _vp],
     "mmu_rowloss_bwd": [_i, _vp, _vp, _i, _f, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "mmu_gather_rows_bf16": [_vp, _vp, _vp, _ll, _i, _i, _vp],
+    "mmu_rowloss_set_streaming": [_i],
+    "mmu_seq_ce_stats": [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "mmu_red_scratch_floats": [],
+    "mmu_mse_fwd": [_vp, _vp, _vp, _ll, _i, _vp, _vp],
+    "mmu_mse_bwd": [_vp, _vp, _vp, _ll, _i, _vp, _vp, _vp],
+    "mmu_seqmean_nsplit": [_i],
+    "mmu_seqmean_fwd": [_vp, _i, _i, _i, _vp, _vp, _vp],
+    "mmu_rmu_pair_fwd": [_vp, _vp, _i, _i, _i, _vp, _vp],
+    "mmu_rmu_pair_bwd": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
     "mmu_l1l0_fwd": [_vp, _vp, _ll, _vp, _vp],
     "mmu_l1_bwd": [_vp, _vp, _ll, _vp, _f, _vp, _vp],
     "mmu_sumsq_bf16": [_vp, _ll, _vp, _vp],
     "mmu_sumsq_scratch_floats": [],
-    "mmu_adamw_bf16": [_vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _f, _i, _vp, _f, _f, _i, _vp],
+    "mmu_adamw_bf16": [_vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _f, _i, _vp, _f, _f, _i, _vp, _i, _vp],
     "mmu_adamw8bit_nblocks": [_ll],
-    "mmu_adamw8bit_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _f, _i, _vp, _f, _f, _i, _vp],
+    "mmu_adamw8bit_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _f, _i, _vp, _f, _f, _i, _vp, _i,
+                           _vp],
     "mmu_scale_bf16": [_vp, _ll, _f, _vp],
 }
 
@@ -477,6 +488,72 @@ def rowloss_bwd(mode, slog, tlog, beta, stats, coef, dlogits):
                                   _p(dlogits), dlogits.stride(0), M, V, _stream()), "mmu_rowloss_bwd")
 
 
+def gather_rows(src2d, rows, dst2d):
+    """dst2d[r] = src2d[rows[r]] (bf16 [n, V] contiguous, rows int64 on the device)."""
+    _bf16c(src2d, dst2d)
+    assert src2d.is_contiguous() and dst2d.is_contiguous() and rows.dtype == torch.int64 and rows.is_cuda and rows.is_contiguous()
+    assert rows.numel() == dst2d.shape[0] and src2d.shape[1] == dst2d.shape[1]
+    _check(load().mmu_gather_rows_bf16(_p(src2d), _p(rows), _p(dst2d), src2d.shape[0], dst2d.shape[0], src2d.shape[1],
+                                       _stream()), "mmu_gather_rows_bf16")
+    return dst2d
+
+
+def rowloss_set_streaming(on: bool):
+    _check(load().mmu_rowloss_set_streaming(int(bool(on))), "mmu_rowloss_set_streaming")
+
+
+def seq_ce_stats(logits, labels):
+    """logits [n, S, V] bf16, labels [n, S] int64 -> float32 [n, 3] = per-sequence {CE sum, #shifted targets, #labels != -100}
+    (mm/eval.py:46-92: get_batch_loss and its token-count normaliser) in one C-ABI call."""
+    _bf16c(logits)
+    n, S, V = logits.shape
+    assert logits.is_contiguous() and labels.dtype == torch.int64 and labels.is_contiguous() and labels.is_cuda
+    scr = torch.empty(2, n * S, device=logits.device, dtype=torch.float32)
+    out = torch.empty(n, 3, device=logits.device, dtype=torch.float32)
+    _check(load().mmu_seq_ce_stats(_p(logits), V, _p(labels), n, S, V, _p(scr[0]), _p(scr[1]), _p(out), _stream()),
+           "mmu_seq_ce_stats")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------- RMU terms
+RED_FLOATS = 1 + 2048  # result in slot 0, per-block partials after it (mmu_red_scratch_floats)
+
+
+def mse_fwd(a, b, cvec, H, out):
+    _bf16c(a, b)
+    assert a.is_contiguous() and (b is None or b.is_contiguous()) and out.dtype == torch.float32 and out.numel() >= RED_FLOATS
+    assert cvec is None or (cvec.dtype == torch.float32 and cvec.numel() == H and cvec.is_cuda)
+    _check(load().mmu_mse_fwd(_p(a), _p(b), _p(cvec), a.numel(), H, _p(out), _stream()), "mmu_mse_fwd")
+
+
+def mse_bwd(a, b, cvec, H, coef, da):
+    _bf16c(a, b, da)
+    assert coef.dtype == torch.float32 and coef.numel() == 1 and da.is_contiguous()
+    _check(load().mmu_mse_bwd(_p(a), _p(b), _p(cvec), a.numel(), H, _p(coef), _p(da), _stream()), "mmu_mse_bwd")
+
+
+def seqmean_fwd(a, mean):
+    _bf16c(a)
+    B, S, H = a.shape
+    assert a.is_contiguous() and mean.dtype == torch.float32 and tuple(mean.shape) == (B, H)
+    part = torch.empty(load().mmu_seqmean_nsplit(S) * B * H, device=a.device, dtype=torch.float32)
+    _check(load().mmu_seqmean_fwd(_p(a), B, S, H, _p(part), _p(mean), _stream()), "mmu_seqmean_fwd")
+    return mean
+
+
+def rmu_pair_fwd(mean, ctrl, out):
+    B, H = mean.shape
+    assert ctrl.dtype == torch.float32 and ctrl.is_contiguous() and ctrl.shape[-1] == H and out.numel() >= RED_FLOATS
+    _check(load().mmu_rmu_pair_fwd(_p(mean), _p(ctrl), B, ctrl.numel() // H, H, _p(out), _stream()), "mmu_rmu_pair_fwd")
+
+
+def rmu_pair_bwd(mean, ctrl, S, coef, da):
+    _bf16c(da)
+    B, H = mean.shape
+    _check(load().mmu_rmu_pair_bwd(_p(mean), _p(ctrl), B, ctrl.numel() // H, S, H, _p(coef), _p(da), _stream()),
+           "mmu_rmu_pair_bwd")
+
+
 # ---------------------------------------------------------------------------------------------- optimiser
 def l1l0_fwd(p, t, out2):
     """out2 (float64[2], zeroed by the caller) += [sum |bf16(p - t)|, #(bf16(p - t) != 0)]; t may be None."""
@@ -501,10 +578,19 @@ def sumsq(g, out):
     _check(load().mmu_sumsq_bf16(_p(g), g.numel(), _p(out), _stream()), "mmu_sumsq_bf16")
 
 
-def adamw(p, g, m, v, lr, beta1, beta2, eps, wd, step, sumsq_t, max_norm, grad_scale=1.0, zero_grad=True):
+def _nodecay_args(nodecay):
+    """nodecay: int64 device tensor [k, 2] of sorted, disjoint [lo, hi) element ranges without weight decay, or None."""
+    if nodecay is None or nodecay.numel() == 0:
+        return 0, 0
+    assert nodecay.dtype == torch.int64 and nodecay.is_cuda and nodecay.is_contiguous() and nodecay.shape[-1] == 2
+    return nodecay.data_ptr(), nodecay.shape[0]
+
+
+def adamw(p, g, m, v, lr, beta1, beta2, eps, wd, step, sumsq_t, max_norm, grad_scale=1.0, zero_grad=True, nodecay=None):
     _bf16c(p, g)
+    nd, nnd = _nodecay_args(nodecay)
     _check(load().mmu_adamw_bf16(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, wd, step,
-                                 _p(sumsq_t), float(max_norm), float(grad_scale), int(zero_grad), _stream()),
+                                 _p(sumsq_t), float(max_norm), float(grad_scale), int(zero_grad), nd, nnd, _stream()),
            "mmu_adamw_bf16")
 
 
@@ -532,14 +618,15 @@ def adamw8bit_nblocks(n: int) -> int:
 
 
 def adamw8bit(p, g, codes1, codes2, absmax1, absmax2, map1, map2, lr, beta1, beta2, eps, wd, step, sumsq_t, max_norm,
-              grad_scale=1.0, zero_grad=True):
+              grad_scale=1.0, zero_grad=True, nodecay=None):
     _bf16c(p, g)
     assert codes1.dtype == torch.uint8 and codes2.dtype == torch.uint8 and codes1.numel() == p.numel() == codes2.numel()
     assert absmax1.dtype == torch.float32 and absmax1.numel() >= adamw8bit_nblocks(p.numel()) == adamw8bit_nblocks(p.numel())
     assert map1.numel() == 256 and map2.numel() == 256 and map1.is_cuda and map2.is_cuda
+    nd, nnd = _nodecay_args(nodecay)
     _check(load().mmu_adamw8bit_bf16(_p(p), _p(g), _p(codes1), _p(codes2), _p(absmax1), _p(absmax2), _p(map1), _p(map2),
                                      p.numel(), lr, beta1, beta2, eps, wd, step, _p(sumsq_t), float(max_norm),
-                                     float(grad_scale), int(zero_grad), _stream()), "mmu_adamw8bit_bf16")
+                                     float(grad_scale), int(zero_grad), nd, nnd, _stream()), "mmu_adamw8bit_bf16")
 
 
 def scale_(x, s):

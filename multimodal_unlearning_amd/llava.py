@@ -237,6 +237,7 @@ class LlavaHIP(nn.Module):
         # engine then reduces what no hook covered).
         self.live_sweeps = 0
         self.capture_layer: Optional[int] = None
+        self.position_ids_mode = "arange"  # or "from_mask" (transformers 4.45.1 left-padding positions); see _positions
         if self.lora:
             self.init_lora_(seed)
 
@@ -570,6 +571,24 @@ class LlavaHIP(nn.Module):
             hs = self._last_capture
         return LlavaOutput(loss=loss, logits=logits, hidden_states=hs)
 
+    def _positions(self, position_ids, attention_mask, B, S):
+        """int32 [B*S] RoPE positions.  None -> `self.position_ids_mode`: "arange" (transformers >= 4.47 / 5.x:
+        modeling_llama.py:386-389) or "from_mask" = cumsum(mask) - 1 with padded slots at 1, what the reference's pinned
+        transformers 4.45.1 LLaVA derives for left-padded rows (`padding_side="left"`, mm/forget.py:54).  The string
+        "from_mask" / "arange" may also be passed per call.  RoPE scores depend on position differences only and left
+        padding shifts a row by a constant, so both give the same function up to the rounding of the bf16 cos / sin
+        tables (tests/golden/trajectory_tiny.npz: HF fp32 differs by 7e-7 between the two)."""
+        dev = self.device
+        mode = position_ids if isinstance(position_ids, str) else (self.position_ids_mode if position_ids is None else None)
+        if mode is None:
+            return position_ids.to(dev, dtype=torch.int32).reshape(-1).contiguous()
+        if mode == "from_mask" and attention_mask is not None:
+            m = attention_mask.to(dev, dtype=torch.int64)
+            return (m.cumsum(-1) - 1).masked_fill(m == 0, 1).to(torch.int32).reshape(-1).contiguous()
+        if mode not in ("arange", "from_mask"):
+            raise ValueError(f"position_ids mode {mode!r}: expected 'arange' or 'from_mask'")
+        return torch.arange(S, device=dev, dtype=torch.int32).repeat(B)
+
     def logits(self, input_ids, attention_mask=None, pixel_values=None, position_ids=None):
         dev = self.device
         kmask = None
@@ -582,10 +601,7 @@ class LlavaHIP(nn.Module):
                 kmask = attention_mask.to(dtype=torch.int32).contiguous()
         ids = input_ids.to(dev, dtype=torch.int64).contiguous()
         B, S = ids.shape
-        if position_ids is None:
-            pos = torch.arange(S, device=dev, dtype=torch.int32).repeat(B)
-        else:
-            pos = position_ids.to(dev, dtype=torch.int32).reshape(-1).contiguous()
+        pos = self._positions(position_ids, attention_mask, B, S)
         pix = None
         if pixel_values is not None and pixel_values.numel() > 0:
             pix = pixel_values.to(dev, dtype=torch.float32).contiguous()
@@ -717,8 +733,7 @@ class LlavaHIP(nn.Module):
                 kmask = attention_mask.to(dev, dtype=torch.int32).contiguous()
         ids = input_ids.to(dev, dtype=torch.int64).contiguous()
         B, S = ids.shape
-        pos = (torch.arange(S, device=dev, dtype=torch.int32).repeat(B) if position_ids is None
-               else position_ids.to(dev, dtype=torch.int32).reshape(-1).contiguous())
+        pos = self._positions(position_ids, attention_mask, B, S)
         pix = None
         if pixel_values is not None and pixel_values.numel() > 0:
             pix = pixel_values.to(dev, dtype=torch.float32).contiguous()

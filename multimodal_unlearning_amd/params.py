@@ -63,6 +63,13 @@ def is_vision(name: str) -> bool:
     return name.startswith("vision.")
 
 
+def no_weight_decay(name: str) -> bool:
+    """True for the tensors transformers.Trainer.create_optimizer puts in its weight_decay = 0 group
+    (`get_decay_parameter_names`: biases and every LayerNorm / RMSNorm weight); Linear and embedding weights — and
+    LoRA's A / B matrices, which are Linear weights in peft — are decayed."""
+    return name.endswith(".bias") or name.endswith(("norm.weight", "ln1.weight", "ln2.weight", "pre_ln.weight"))
+
+
 def init_params(cfg: LlavaConfig, seed: int = 0, std: float = 0.02, dtype=torch.float32) -> "OrderedDict[str, torch.Tensor]":
     """Framework-independent deterministic init (numpy PCG64 stream, in param_specs order):
     matrices / embeddings ~ N(0, std^2); norm weights 1 (+ small jitter so tests see them); biases ~ N(0, std^2).

@@ -52,8 +52,71 @@ class _L1L0Fn(torch.autograd.Function):
         return None, None, None, None, None
 
 
+class _MseFn(torch.autograd.Function):
+    """mse_loss(act, ref) over a captured activation [B,S,H] bf16 with ref = another activation (RMU's retain term,
+    mm/trainer.py:321-324) or a control vector [H] broadcast over every token (the text trainer's forget term,
+    nlp/dataloader.py:355): HIP kernels mmu_mse_fwd / mmu_mse_bwd, fp32 math, deterministic reduction."""
+
+    @staticmethod
+    def forward(ctx, act, ref, cvec):
+        from . import hip
+
+        act = act.contiguous()
+        H = act.shape[-1]
+        out = torch.empty(hip.RED_FLOATS, device=act.device, dtype=torch.float32)
+        hip.mse_fwd(act, ref, cvec, H, out)
+        ctx.save_for_backward(act, ref, cvec)
+        return out[0] / act.numel()
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import hip
+
+        act, ref, cvec = ctx.saved_tensors
+        coef = (g.detach().float() * (2.0 / act.numel())).reshape(1).contiguous()
+        da = torch.empty_like(act)
+        hip.mse_bwd(act, ref, cvec, act.shape[-1], coef, da)
+        return da, None, None
+
+
+class _RmuForgetFn(torch.autograd.Function):
+    """mm RMU forget term: mse_loss(act.mean(dim=1) [B,H], control [Bc,1,H]) — which broadcasts to [Bc,B,H], a quirk of
+    mm/trainer.py:316 kept on purpose — as mmu_seqmean_fwd + mmu_rmu_pair_fwd; backward writes the [B,S,H] gradient of
+    the captured activation in one pass (mmu_rmu_pair_bwd)."""
+
+    @staticmethod
+    def forward(ctx, act, ctrl):
+        from . import hip
+
+        act = act.contiguous()
+        B, S, H = act.shape
+        mean = torch.empty(B, H, device=act.device, dtype=torch.float32)
+        hip.seqmean_fwd(act, mean)
+        out = torch.empty(hip.RED_FLOATS, device=act.device, dtype=torch.float32)
+        hip.rmu_pair_fwd(mean, ctrl, out)
+        ctx.save_for_backward(mean, ctrl)
+        ctx.meta = (S, B * (ctrl.numel() // H) * H, act.dtype)
+        return out[0] / ctx.meta[1]
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import hip
+
+        mean, ctrl = ctx.saved_tensors
+        S, n, dt = ctx.meta
+        coef = (g.detach().float() * (2.0 / n)).reshape(1).contiguous()
+        da = torch.empty(mean.shape[0], S, mean.shape[1], device=mean.device, dtype=dt)
+        hip.rmu_pair_bwd(mean, ctrl, S, coef, da)
+        return da, None
+
+
 class MMTrainerForgetting:
     def __init__(self, *args, **kwargs):
+        self._pop_forget_kwargs(kwargs)
+        self._init_host(*args, **kwargs)
+
+    def _pop_forget_kwargs(self, kwargs):
+        """The plug-in's own constructor arguments (mm/trainer.py:113-123); what is left belongs to the host loop."""
         self.loss_type = kwargs.pop("forget_loss").lower()
         self.teacher_model = kwargs.pop("teacher_model", None)
         self.loss_beta = kwargs.pop("loss_beta", 1.0)
@@ -63,12 +126,6 @@ class MMTrainerForgetting:
         self.loss_args = kwargs.pop("loss_args", {}) or {}
         if self.l1_lambda and self.l1_lambda != 0 and self.l_norm_from not in ("zero", "init"):
             raise ValueError(f"Invalid l_norm_from {self.l_norm_from}, should be 'zero' or 'init'")
-        # HF-Trainer style positional/keyword leftovers (model, args, train_dataset, data_collator, tokenizer ...)
-        self.model = kwargs.pop("model", args[0] if args else None)
-        self.args = kwargs.pop("args", None)
-        self.train_dataset = kwargs.pop("train_dataset", None)
-        self.data_collator = kwargs.pop("data_collator", None)
-        self.tokenizer = kwargs.pop("tokenizer", None)
         self.fuse_pairs = bool(self.loss_args.get("fuse_pairs", True))
         self.control_vec = None
         self.is_deepspeed_enabled = False
@@ -77,6 +134,15 @@ class MMTrainerForgetting:
         if self.teacher_model is not None and hasattr(self.teacher_model, "parameters"):
             for p in self.teacher_model.parameters():  # mm/trainer.py:157-160
                 p.requires_grad = False
+
+    def _init_host(self, *args, **kwargs):
+        """Stand-alone use (our ForgetEngine drives the loop): keep the HF-Trainer style leftovers as attributes.
+        `hosted_by_hf_trainer()` replaces this with transformers.Trainer.__init__ (mm/trainer.py:125)."""
+        self.model = kwargs.pop("model", args[0] if args else None)
+        self.args = kwargs.pop("args", None)
+        self.train_dataset = kwargs.pop("train_dataset", None)
+        self.data_collator = kwargs.pop("data_collator", None)
+        self.tokenizer = kwargs.pop("tokenizer", None)
 
     @staticmethod
     def to_device(device, inputs):  # mm/trainer.py:164-166
@@ -231,17 +297,19 @@ class MMTrainerForgetting:
             # (forget) + MSE to the teacher's activation (retain).  The hidden-state sweep stops at that layer.
             layer = int(self.loss_args.get("rmu_layer", 7))
             strip = lambda d: {k: v for k, v in d.items() if k != "labels"}
-            forget_act = model.hidden_states(layer, **strip(forget_inputs)).float()
+            forget_act = model.hidden_states(layer, **strip(forget_inputs))
             if getattr(self, "control_vec", None) is None:
-                rand_vec = torch.rand(forget_act.shape[0], 1, forget_act.shape[-1], dtype=forget_act.dtype,
+                rand_vec = torch.rand(forget_act.shape[0], 1, forget_act.shape[-1], dtype=torch.float32,
                                       device=forget_act.device)
                 self.control_vec = rand_vec / torch.norm(rand_vec) * 300
-            # NOTE the reference's shapes: input [B,H] vs target [B,1,H] broadcast to [B,B,H] (kept on purpose)
-            forget_loss = torch.nn.functional.mse_loss(forget_act.mean(dim=1), self.control_vec.to(forget_act.device)) * beta
-            retain_act = model.hidden_states(layer, **strip(retain_inputs)).float()
+            retain_act = model.hidden_states(layer, **strip(retain_inputs))
             with torch.no_grad():
-                oracle_act = self.teacher_model.hidden_states(layer, **strip(retain_inputs)).float()
-            retain_loss = torch.nn.functional.mse_loss(retain_act, oracle_act)
+                oracle_act = self.teacher_model.hidden_states(layer, **strip(retain_inputs))
+            # fused mean-over-sequence + MSE kernels on the bf16 activations (no eager substitute: the kernels reject
+            # anything but device bf16).  NOTE the reference's shapes: input [B,H] vs target [B,1,H] broadcast to [B,B,H]
+            ctrl = self.control_vec.to(forget_act.device, torch.float32).reshape(-1, forget_act.shape[-1]).contiguous()
+            forget_loss = _RmuForgetFn.apply(forget_act, ctrl) * beta
+            retain_loss = _MseFn.apply(retain_act, oracle_act.contiguous(), None)
             loss = forget_loss + retain_loss
 
         else:
@@ -347,16 +415,16 @@ class CustomTrainerForgetting(MMTrainerForgetting):
         elif lt == "RMU":
             layer = int(self.loss_args.get("rmu_layer", 7))
             strip = lambda d: {k: v for k, v in d.items() if k != "labels"}
-            fa = model.hidden_states(layer, **strip(f)).float()
+            fa = model.hidden_states(layer, **strip(f))
             cv = self.control_vec
             if cv is None:  # the text trainer draws a new vector on every call (nlp/dataloader.py:347-354)
-                rand_vec = torch.rand(1, 1, fa.shape[-1], dtype=fa.dtype, device=fa.device)
+                rand_vec = torch.rand(1, 1, fa.shape[-1], dtype=torch.float32, device=fa.device)
                 cv = rand_vec / torch.norm(rand_vec) * 300
-            forget_loss = torch.nn.functional.mse_loss(fa, cv.to(fa.device).expand_as(fa)) * beta
-            ra = model.hidden_states(layer, **strip(r)).float()
+            ra = model.hidden_states(layer, **strip(r))
             with torch.no_grad():
-                oa = self.oracle_model.hidden_states(layer, **strip(r)).float()
-            loss = forget_loss + torch.nn.functional.mse_loss(ra, oa)
+                oa = self.oracle_model.hidden_states(layer, **strip(r))
+            cvec = cv.to(fa.device, torch.float32).reshape(-1).contiguous()
+            loss = _MseFn.apply(fa, None, cvec) * beta + _MseFn.apply(ra, oa.contiguous(), None)
         elif lt in ("retain_ft", "grad_ascent", "scrub", "eco_ft", "dpo", "KL", "LLMU") or lt.startswith("grad_diff"):
             # identical arithmetic to the mm dispatcher (whose names are the lower-cased ones; "forget_KL" -> "forget_kl")
             keep, self.loss_type = self.loss_type, lt.lower()
@@ -371,3 +439,23 @@ class CustomTrainerForgetting(MMTrainerForgetting):
             raise ValueError(f"Invalid loss type {lt}")
         loss = loss + self._l_norm_regulariser(model)
         return (loss, outputs) if return_outputs else loss
+
+
+def hosted_by_hf_trainer(plugin=MMTrainerForgetting):
+    """The plug-in as a real `transformers.Trainer` subclass — the reference's arrangement (`class
+    MMTrainerForgetting(Trainer)`, mm/trainer.py:112; built at mm/forget.py:171-187): HF's loop (`training_step`,
+    gradient accumulation, clipping, optimiser, scheduler, logging) calls this class's `compute_loss` /
+    `prediction_step`.  Usage: `hosted_by_hf_trainer()(model=..., args=TrainingArguments(...), train_dataset=...,
+    data_collator=..., forget_loss=..., teacher_model=..., ...)`.  transformers is imported here, not at module import:
+    the stand-alone path (ForgetEngine) does not need it."""
+    import transformers
+
+    class Hosted(plugin, transformers.Trainer):
+        def _init_host(self, *args, **kwargs):
+            transformers.Trainer.__init__(self, *args, **kwargs)
+            # the reference's pinned transformers (4.45.1) divides every micro-batch loss by the accumulation steps;
+            # 5.x skips that for models whose forward takes **kwargs unless this is False
+            self.model_accepts_loss_kwargs = False
+
+    Hosted.__name__ = Hosted.__qualname__ = plugin.__name__ + "HF"
+    return Hosted

@@ -55,21 +55,35 @@ def get_batch_loss(output, labels):
     return sequence_ce_sums(output, labels.to(output.device))
 
 
-def remove_image_tokens(input_ids, logits, image_token_id):
-    """mm/trainer_utils.py:48-70.  With pre-expanded <image> ids (transformers >= 4.47 processors, and every batch
-    this repo builds) logits and ids have the same length and the function is the identity; the general slicing
-    is kept for un-expanded ids."""
+def image_token_source_rows(input_ids, n_logit_rows: int, image_token_id):
+    """Index arithmetic of mm/trainer_utils.py:48-70 for the whole batch at once, on the device of `input_ids`: for every
+    sequence and every kept position t < T, the position inside its L = n_logit_rows logits rows that the reference
+    keeps — the first `start` rows (start = column of the sequence's first <image> id) and the last T - start rows; a
+    sequence without an image keeps its last T rows.  Returns int64 [B, T]."""
     B, T = input_ids.shape
-    if logits.shape[1] == T:
+    is_img = input_ids == image_token_id
+    start = torch.where(is_img.any(dim=1), is_img.to(torch.int64).argmax(dim=1), torch.zeros(B, dtype=torch.int64,
+                                                                                               device=input_ids.device))
+    t = torch.arange(T, device=input_ids.device, dtype=torch.int64)[None]
+    return torch.where(t < start[:, None], t, n_logit_rows - T + t)
+
+
+def remove_image_tokens(input_ids, logits, image_token_id):
+    """mm/trainer_utils.py:48-70: align logits [B, L, V] of a model that expands ONE <image> id into its patch
+    positions (transformers 4.45.1) with the un-expanded `input_ids` [B, T].  With pre-expanded ids (transformers >=
+    4.47 processors, and every batch this repo builds) L == T and the function is the identity, as in the reference.
+    The general case has no host loop and no device sync: the kept rows are computed for the whole batch on the
+    device and copied by one row-gather kernel (bf16 device logits; other tensors — the helper's own fp32 CPU
+    fixture — go through the same indices with torch indexing)."""
+    B, T = input_ids.shape
+    L = logits.shape[1]
+    if L == T:
         return logits
-    search = (input_ids == image_token_id).nonzero(as_tuple=True)
-    has = search[0].tolist()
-    idx = search[1].tolist()
-    res = []
-    for i in range(B):
-        if i not in has:
-            res.append(logits[i, -T:, :])
-            continue
-        start = idx[has.index(i)]
-        res.append(torch.cat([logits[i, :start, :], logits[i, -(T - start):, :]]))
-    return torch.stack(res)
+    pos = image_token_source_rows(input_ids.to(logits.device), L, image_token_id)  # [B, T]
+    if logits.is_cuda and logits.dtype == torch.bfloat16 and logits.shape[-1] % 8 == 0:
+        V = logits.shape[-1]
+        rows = (pos + torch.arange(B, device=pos.device, dtype=torch.int64)[:, None] * L).reshape(-1).contiguous()
+        out = torch.empty(B, T, V, device=logits.device, dtype=logits.dtype)
+        hip.gather_rows(logits.contiguous().view(B * L, V), rows, out.view(B * T, V))
+        return out
+    return logits[torch.arange(B, device=logits.device)[:, None], pos]

@@ -800,3 +800,110 @@ def test_c_abi_from_a_native_caller(dev, tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
     assert "c-abi caller ok" in r.stdout
+
+
+# ------------------------------------------------------- round-2 kernels: one-pass row loss, RMU terms, eval stats
+@pytest.mark.parametrize("mode", [hip.KL_STUDENT_INPUT, hip.KL_TEACHER_INPUT, hip.NPO, hip.ENTROPY])
+@pytest.mark.parametrize("V", [32064, 520])
+def test_rowloss_register_resident_equals_streaming(dev, mode, V):
+    """The one-pass kernel (rows held in registers, every logit read once) vs the two-walk streaming kernel: same
+    per-element arithmetic, different summation order over threads -> equal to fp32 rounding of the row sums."""
+    M = 37
+    s, t = _randn((M, V), dev, 2.0, seed=1), _randn((M, V), dev, 2.0, seed=2)
+    st_r = torch.zeros(M, 4, device=dev)
+    st_s = torch.zeros(M, 4, device=dev)
+    tt = None if mode == hip.ENTROPY else t
+    hip.rowloss_fwd(mode, s, tt, 0.7, st_r)
+    hip.rowloss_set_streaming(True)
+    try:
+        hip.rowloss_fwd(mode, s, tt, 0.7, st_s)
+    finally:
+        hip.rowloss_set_streaming(False)
+    assert torch.allclose(st_r[:, :2], st_s[:, :2], rtol=1e-6, atol=1e-6)        # the two log-sum-exps
+    assert torch.allclose(st_r[:, 2:], st_s[:, 2:], rtol=2e-5, atol=2e-5 * V ** 0.5)  # row value / aux sums
+
+
+def test_rmu_terms_vs_torch(dev):
+    """mmu_seqmean / mmu_rmu_pair / mmu_mse (fwd + bwd) vs the reference's expressions in fp32 torch:
+    mse_loss(act.mean(1), control [B,1,H]) (-> [B,B,H] broadcast, mm/trainer.py:316) and mse_loss(act, other)."""
+    import torch.nn.functional as F
+
+    from multimodal_unlearning_amd.trainer import _MseFn, _RmuForgetFn
+
+    B, S, H = 3, 150, 1024 + 512
+    act = _randn((B, S, H), dev, 1.5, seed=3)
+    other = _randn((B, S, H), dev, 1.5, seed=4)
+    rand = torch.rand(B, 1, H, generator=torch.Generator().manual_seed(5))
+    ctrl = (rand / torch.norm(rand) * 300).to(dev)
+    a1 = act.clone().requires_grad_(True)
+    loss = _RmuForgetFn.apply(a1, ctrl.reshape(B, H).contiguous()) * 0.7
+    loss.backward()
+    a2 = act.float().requires_grad_(True)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref = F.mse_loss(a2.mean(dim=1), ctrl) * 0.7
+    ref.backward()
+    assert abs(loss.item() - ref.item()) < 1e-5 * abs(ref.item())
+    assert _relerr(a1.grad, a2.grad) < 4e-3  # bf16 rounding of the gradient
+    a3 = act.clone().requires_grad_(True)
+    l2 = _MseFn.apply(a3, other, None)
+    l2.backward()
+    a4 = act.float().requires_grad_(True)
+    r2 = F.mse_loss(a4, other.float())
+    r2.backward()
+    assert abs(l2.item() - r2.item()) < 1e-5 * r2.item() and _relerr(a3.grad, a4.grad) < 4e-3
+    cvec = ctrl[0, 0].contiguous()
+    a5 = act.clone().requires_grad_(True)
+    l3 = _MseFn.apply(a5, None, cvec)
+    l3.backward()
+    a6 = act.float().requires_grad_(True)
+    r3 = F.mse_loss(a6, cvec.expand_as(a6))
+    r3.backward()
+    assert abs(l3.item() - r3.item()) < 1e-5 * r3.item() and _relerr(a5.grad, a6.grad) < 4e-3
+    # deterministic: the same bits on a second call
+    l2b = _MseFn.apply(act, other, None)
+    assert l2b.item() == l2.item()
+
+
+def test_seq_ce_stats_vs_torch(dev):
+    import torch.nn.functional as F
+
+    n, S, V = 5, 33, 520
+    logits = _randn((n, S, V), dev, 2.0, seed=6)
+    labels = torch.randint(0, V, (n, S), generator=torch.Generator().manual_seed(7))
+    labels[:, :9] = -100
+    labels[2, 20:] = -100
+    labels[3, 0] = 4  # a supervised FIRST token counts in the unshifted count only
+    st = hip.seq_ce_stats(logits, labels.to(dev)).cpu()
+    lf = logits.float().cpu()
+    ref = F.cross_entropy(lf[:, :-1].transpose(1, 2), labels[:, 1:], ignore_index=-100, reduction="none").sum(-1)
+    assert torch.allclose(st[:, 0], ref, rtol=1e-5, atol=1e-4)
+    assert st[:, 1].tolist() == (labels[:, 1:] != -100).sum(-1).float().tolist()
+    assert st[:, 2].tolist() == (labels != -100).sum(-1).float().tolist()
+
+
+def test_remove_image_tokens_device_path(dev):
+    """bf16 device logits go through the row-gather kernel: same rows as the reference's slicing (golden I/O pair of
+    mm/trainer_utils.py:48-70, V padded from 17 to 24 columns for 16-byte rows)."""
+    import os
+
+    from multimodal_unlearning_amd import trainer_utils as tu
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "trainer_utils.npz"))
+    lg = torch.zeros(3, 9, 24)
+    lg[..., :17] = torch.from_numpy(g["logits"])
+    lgd = lg.to(dev).to(BF)
+    ids = torch.from_numpy(g["ids"]).to(dev)
+    out = tu.remove_image_tokens(ids, lgd, 16)
+    exp = torch.from_numpy(g["rm_image"]).to(BF)
+    assert out.shape == (3, 6, 24) and torch.equal(out[..., :17].cpu(), exp)
+    # larger ragged case vs torch indexing
+    B, T, L, V = 7, 40, 615, 256
+    big = _randn((B, L, V), dev, 1.0, seed=8)
+    ids = torch.randint(0, 90, (B, T), generator=torch.Generator().manual_seed(9))
+    for b, c in ((0, 1), (2, 17), (3, 39), (5, 0)):
+        ids[b, c] = 99
+    got = tu.remove_image_tokens(ids.to(dev), big, 99)
+    pos = tu.image_token_source_rows(ids, L, 99)
+    assert torch.equal(got.cpu(), big.cpu()[torch.arange(B)[:, None], pos])

@@ -585,3 +585,143 @@ def test_full_width_properties(dev):
     n_sup = int((batch["retain"]["labels"][:, 1:] != -100).sum())
     assert abs(float(sums.sum()) / n_sup - float(out.loss)) < 2e-3 * float(out.loss)
     assert out.logits.shape == (2, S, cfg.text.vocab_size)
+
+
+# ------------------------------------------------------------------------------------- step loop
+def test_engine_trajectory_vs_hf_trainer_golden(dev):
+    """ForgetEngine (GA, clip 1.0, HIP AdamW with HF's no-decay groups, k-th update at lambda(k-1)) against the
+    trajectory of the REFERENCE's MMTrainerForgetting inside the real transformers.Trainer.train() (fp32, torch AdamW;
+    tests/golden/trajectory_tiny.npz, oracle/make_golden_trajectory.py).  bf16 parameters + bf16 gradients vs fp32:
+    lr exact; mean loss |d| < 2e-3; unclipped gradient norm 2e-2; the parameter-norm DRIFT from step to step 15 %."""
+    from multimodal_unlearning_amd.engine import ForgetEngine
+    from multimodal_unlearning_amd.llava import LlavaHIP
+    from multimodal_unlearning_amd.trainer import MMTrainerForgetting
+
+    g = np.load(os.path.join(G, "trajectory_tiny.npz"))
+    cfg = tiny_test_config()
+    model = LlavaHIP(cfg, init_params(cfg, seed=0), device=dev)
+    ga, steps, warm = int(g["ga"]), int(g["steps"]), int(g["warmup"])
+    tr = MMTrainerForgetting(model=model, forget_loss=str(g["loss_type"]), teacher_model=None, loss_beta=1.0, l1_lambda=0,
+                             l0_lambda=0, l_norm_from="zero")
+    eng = ForgetEngine(model, tr, ForgetConfig(lr=float(g["lr0"]), weight_decay=float(g["wd"])), total_steps=steps,
+                       warmup_steps=warm)
+    mbs = [{s: {k: torch.from_numpy(g[f"mb{i}.{s}.{k}"]) for k in KEYS} for s in ("forget", "retain")}
+           for i in range(ga * steps)]
+    pn_prev = model.train_flat.detach().float().norm().item()
+    ref_prev = None
+    for k in range(steps):
+        st = eng.step(mbs[k * ga:(k + 1) * ga], sync_loss=True)
+        gn = float(eng.sumsq[0].sqrt())  # norm of the accumulated (already / GA) gradient, before clipping
+        pn = model.train_flat.detach().float().norm().item()
+        assert st.lr == pytest.approx(float(g["lr"][k]), rel=1e-6, abs=1e-12), (k, st.lr)
+        assert abs(st.loss - float(g["loss"][k])) < 2e-3, (k, st.loss, float(g["loss"][k]))
+        assert abs(gn - float(g["gnorm"][k])) < 2e-2 * float(g["gnorm"][k]), (k, gn, float(g["gnorm"][k]))
+        if ref_prev is not None and abs(float(g["pnorm"][k]) - ref_prev) > 1e-3:
+            d, rd = pn - pn_prev, float(g["pnorm"][k]) - ref_prev
+            assert abs(d - rd) < 0.15 * abs(rd) + 2e-4, (k, d, rd)
+        pn_prev, ref_prev = pn, float(g["pnorm"][k])
+
+
+def test_adamw_nodecay_ranges_match_torch_param_groups(dev):
+    """mmu_adamw_bf16's no-decay table = torch AdamW with a weight_decay = 0 parameter group (HF create_optimizer)."""
+    from multimodal_unlearning_amd import hip
+
+    n = 4096 * 3
+    gen = torch.Generator(device=dev).manual_seed(5)
+    p0 = torch.randn(n, device=dev, generator=gen).to(torch.bfloat16)
+    gr = (torch.randn(n, device=dev, generator=gen) * 0.1).to(torch.bfloat16)
+    ranges = [(64, 1024), (4096, 4096 + 8), (n - 2048, n)]
+    nd = torch.tensor(ranges, device=dev, dtype=torch.int64)
+    mask = torch.zeros(n, dtype=torch.bool, device=dev)
+    for a, b in ranges:
+        mask[a:b] = True
+    pa = torch.nn.Parameter(p0.float()[~mask].clone())
+    pb = torch.nn.Parameter(p0.float()[mask].clone())
+    opt = torch.optim.AdamW([{"params": [pa], "weight_decay": 0.5}, {"params": [pb], "weight_decay": 0.0}], lr=1e-2,
+                            betas=(0.9, 0.95), eps=1e-8)
+    pa.grad, pb.grad = gr.float()[~mask].clone(), gr.float()[mask].clone()
+    opt.step()
+    ref = torch.empty(n, device=dev)
+    ref[~mask], ref[mask] = pa.detach(), pb.detach()
+    p = p0.clone()
+    m, v = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    hip.adamw(p, gr.clone(), m, v, 1e-2, 0.9, 0.95, 1e-8, 0.5, 1, None, 0.0, 1.0, False, nodecay=nd)
+    # one update from the same bf16 values: the kernel result is the bf16 rounding of torch's fp32 result (1 ulp slack)
+    assert (p.float() - ref).abs().max().item() <= 2 ** -7 * ref.abs().max().item()
+    assert (p.float() - ref)[mask].abs().max().item() <= 2 ** -8 * ref[mask].abs().max().item()
+    # decayed and undecayed elements really differ: with a zero gradient only the decayed ones shrink
+    q = p0.clone()
+    hip.adamw(q, torch.zeros_like(gr), torch.zeros(n, device=dev), torch.zeros(n, device=dev), 1e-2, 0.9, 0.95, 1e-8, 0.5, 1,
+              None, 0.0, 1.0, False, nodecay=nd)
+    assert torch.equal(q[mask], p0[mask]) and not torch.equal(q[~mask], p0[~mask])
+    q2 = p0.clone()
+    hip.adamw(q2, torch.zeros_like(gr), torch.zeros(n, device=dev), torch.zeros(n, device=dev), 1e-2, 0.9, 0.95, 1e-8, 0.5, 1,
+              None, 0.0, 1.0, False)
+    assert torch.equal(q2[~mask], q[~mask]) and not torch.equal(q2[mask], p0[mask])
+
+
+def test_position_ids_from_mask_equals_arange_up_to_rounding(models):
+    """transformers 4.45.1's mask-derived positions for left-padded rows vs arange (5.x): RoPE is relative, so the two are
+    one function; the HIP path agrees with the HF fp32 fixture in both modes and with itself to bf16 table rounding."""
+    cfg, P, student, _ = models
+    g = np.load(os.path.join(G, "trajectory_tiny.npz"))
+    sp = {k: torch.from_numpy(g[f"pos.in.{k}"]) for k in KEYS}
+    valid = sp["attention_mask"].bool()
+    ref = torch.from_numpy(g["pos.logits"])
+    outs = {}
+    for mode in ("arange", "from_mask"):
+        with torch.no_grad():
+            out = student(**sp, position_ids=mode)
+        outs[mode] = out
+        assert _relerr(out.logits.cpu()[valid], ref[valid]) < 1e-2, mode
+        assert abs(out.loss.item() - float(g["pos.loss"])) < 1e-3 * max(1.0, float(g["pos.loss"]))
+    with torch.no_grad():
+        explicit = student(**sp, position_ids=torch.from_numpy(g["pos.position_ids"]))
+    assert torch.equal(explicit.logits, outs["from_mask"].logits)
+    assert not torch.equal(outs["arange"].logits, outs["from_mask"].logits)  # different table rows were read
+    student.position_ids_mode = "from_mask"
+    try:
+        with torch.no_grad():
+            assert torch.equal(student(**sp).logits, outs["from_mask"].logits)
+    finally:
+        student.position_ids_mode = "arange"
+    with pytest.raises(ValueError):
+        student(**sp, position_ids="bogus")
+
+
+def test_compute_loss_under_hf_trainer(dev):
+    """The plug-in hosted by a real transformers.Trainer on the HIP model (mm/trainer.py:112): HF's training_step
+    (prepare inputs, autocast, compute_loss, loss / GA, accelerator.backward) must leave the same gradient in the flat
+    buffer as the stand-alone call, and trainer.train() must run optimiser steps on the flat parameter."""
+    import tempfile
+
+    import transformers
+
+    from multimodal_unlearning_amd.llava import LlavaHIP
+    from multimodal_unlearning_amd.trainer import MMTrainerForgetting, hosted_by_hf_trainer
+
+    cfg = tiny_test_config()
+    model = LlavaHIP(cfg, init_params(cfg, seed=0), device=dev)
+    data = [make_forget_batch(cfg, 2, 32, seed=900 + i, n_question=5) for i in range(4)]
+    kw = dict(forget_loss="grad_diff_forget_ce_retain_ce", teacher_model=None, loss_beta=1.0, l1_lambda=0, l0_lambda=0,
+              l_norm_from="zero", loss_args={})
+    args = transformers.TrainingArguments(output_dir=tempfile.mkdtemp(), per_device_train_batch_size=1,
+                                          gradient_accumulation_steps=2, max_steps=2, learning_rate=1e-3, bf16=True,
+                                          report_to=[], remove_unused_columns=False, disable_tqdm=True,
+                                          save_strategy="no", optim="adamw_torch")
+    tr = hosted_by_hf_trainer()(model=model, args=args, train_dataset=data, data_collator=lambda x: x[0], **kw)
+    tr.current_gradient_accumulation_steps = 2
+    model.ensure_grad().zero_()
+    hf_loss = tr.training_step(model, data[0])
+    g_hf = model.ensure_grad().clone()
+    model.ensure_grad().zero_()
+    ours = MMTrainerForgetting(model=model, **kw).compute_loss(model, data[0])
+    (ours / 2).backward()
+    assert float(hf_loss) == pytest.approx(float(ours) / 2, rel=1e-5)
+    assert torch.equal(g_hf, model.ensure_grad())
+    model.ensure_grad().zero_()
+    before = model.train_flat.detach().clone()
+    tr.train()
+    assert tr.state.global_step == 2
+    assert not torch.equal(before, model.train_flat.detach())
+    assert torch.isfinite(model.train_flat.detach().float()).all()
