@@ -16,10 +16,71 @@ from .config import LlavaConfig
 from .params import detect_hf_style, from_hf_state_dict, to_hf_state_dict
 
 
+def hf_config_dict(cfg: LlavaConfig, dtype=torch.bfloat16) -> dict:
+    """The `config.json` transformers needs to rebuild the model (`AutoModelForPreTraining.from_pretrained(save_dir)` in
+    mm/eval.py reads it): a LlavaConfig with its CLIP vision_config and Llama text_config."""
+    v, t = cfg.vision, cfg.text
+    return {
+        "architectures": ["LlavaForConditionalGeneration"], "model_type": "llava",
+        "image_token_index": cfg.image_token_index, "image_seq_length": v.num_patches,
+        "vision_feature_layer": cfg.vision_feature_layer, "vision_feature_select_strategy": "default",
+        "projector_hidden_act": "gelu", "multimodal_projector_bias": True, "tie_word_embeddings": False,
+        "torch_dtype": str(dtype).replace("torch.", ""),
+        "vision_config": {"model_type": "clip_vision_model", "hidden_size": v.hidden_size,
+                          "intermediate_size": v.intermediate_size, "num_hidden_layers": v.num_layers,
+                          "num_attention_heads": v.num_heads, "image_size": v.image_size, "patch_size": v.patch_size,
+                          "num_channels": v.num_channels, "layer_norm_eps": v.layer_norm_eps, "hidden_act": "quick_gelu",
+                          "projection_dim": 768, "vocab_size": 32000},
+        "text_config": {"model_type": "llama", "architectures": ["LlamaForCausalLM"], "hidden_size": t.hidden_size,
+                        "intermediate_size": t.intermediate_size, "num_hidden_layers": t.num_layers,
+                        "num_attention_heads": t.num_heads, "num_key_value_heads": t.num_heads,
+                        "vocab_size": t.vocab_size, "rms_norm_eps": t.rms_norm_eps, "rope_theta": t.rope_theta,
+                        "max_position_embeddings": t.max_position, "hidden_act": "silu", "attention_bias": False,
+                        "mlp_bias": False, "tie_word_embeddings": False,
+                        "torch_dtype": str(dtype).replace("torch.", "")},
+    }
+
+
+def unused_hf_tensor_shapes(cfg: LlavaConfig, style: str):
+    """HF parameters the forget step never reads (so our fused layout does not hold them): the CLIP layers after the
+    feature layer (one of 24 for LLaVA-1.5) and `post_layernorm`.  name -> shape, in HF order."""
+    from .params import _hf_prefixes
+
+    vt = _hf_prefixes(style)[0]
+    v = cfg.vision
+    dv, iv = v.hidden_size, v.intermediate_size
+    out = OrderedDict()
+    for i in range(cfg.vision_layers_used, v.num_layers):
+        h = vt + f"encoder.layers.{i}."
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            out[h + f"self_attn.{n}.weight"], out[h + f"self_attn.{n}.bias"] = (dv, dv), (dv,)
+        for n in ("layer_norm1", "layer_norm2"):
+            out[h + n + ".weight"], out[h + n + ".bias"] = (dv,), (dv,)
+        out[h + "mlp.fc1.weight"], out[h + "mlp.fc1.bias"] = (iv, dv), (iv,)
+        out[h + "mlp.fc2.weight"], out[h + "mlp.fc2.bias"] = (dv, iv), (dv,)
+    out[vt + "post_layernorm.weight"], out[vt + "post_layernorm.bias"] = (dv,), (dv,)
+    return out
+
+
 def save_pretrained(cfg: LlavaConfig, params, out_dir: str, style: str = "hf4", max_shard_bytes: int = 5 << 30,
-                    dtype=torch.bfloat16, lora_state=None):
+                    dtype=torch.bfloat16, lora_state=None, extra=None, lora_r: int = 8, lora_alpha: float = 32.0):
+    """`model.save_pretrained(save_dir)` (mm/forget.py:193-195) for the replica: safetensors shards with transformers'
+    tensor names, `config.json` (LlavaConfig) and `generation_config.json`, so the reference's eval
+    (`from_pretrained(save_dir)`, mm/eval.py) loads the directory with no missing key.  `extra`: the HF tensors
+    `load_pretrained(..., return_extra=True)` set aside (unused last CLIP layer, post_layernorm) — written back
+    unchanged; without it (a model that never came from an HF checkpoint) those entries are written as identity
+    LayerNorms / zero Linears and listed under "synthesized_keys" in mmu_config.json.  `lora_state` (compact fused
+    tensors of LlavaHIP.lora_state()) goes to peft's layout: adapter_model.safetensors + adapter_config.json."""
     os.makedirs(out_dir, exist_ok=True)
     sd = to_hf_state_dict(cfg, params, style)
+    synthesized = []
+    for k, shape in unused_hf_tensor_shapes(cfg, style).items():
+        if extra is not None and k in extra:
+            sd[k] = extra[k]
+        else:
+            sd[k] = torch.ones(shape) if k.endswith(("layer_norm1.weight", "layer_norm2.weight", "post_layernorm.weight")) \
+                else torch.zeros(shape)
+            synthesized.append(k)
     shards, cur, cur_bytes = [], OrderedDict(), 0
     for k, v in sd.items():
         t = v.detach().to(dtype).contiguous().cpu()
@@ -41,14 +102,20 @@ def save_pretrained(cfg: LlavaConfig, params, out_dir: str, style: str = "hf4", 
     if n > 1:
         json.dump({"metadata": {"total_size": sum(t.numel() * t.element_size() for sh in shards for t in sh.values())},
                    "weight_map": weight_map}, open(os.path.join(out_dir, "model.safetensors.index.json"), "w"), indent=2)
-    json.dump(cfg.to_dict(), open(os.path.join(out_dir, "mmu_config.json"), "w"), indent=2)
+    json.dump(hf_config_dict(cfg, dtype), open(os.path.join(out_dir, "config.json"), "w"), indent=2)
+    json.dump({"_from_model_config": True, "bos_token_id": 1, "eos_token_id": 2, "pad_token_id": 32001},
+              open(os.path.join(out_dir, "generation_config.json"), "w"), indent=2)
+    mc = cfg.to_dict()
+    mc["hf_tensor_names"], mc["synthesized_keys"] = style, synthesized
+    json.dump(mc, open(os.path.join(out_dir, "mmu_config.json"), "w"), indent=2)
     if lora_state:
-        save_file({k: v.contiguous() for k, v in lora_state.items()}, os.path.join(out_dir, "adapter_model.safetensors"))
+        save_adapter(cfg, lora_state, out_dir, r=lora_r, alpha=lora_alpha, style=style)
     return sorted(set(weight_map.values()))
 
 
-def load_pretrained(cfg: LlavaConfig, path: str):
-    """Read every *.safetensors shard under `path` (index file optional) and return params in our fused layout."""
+def load_pretrained(cfg: LlavaConfig, path: str, return_extra: bool = False):
+    """Read every *.safetensors shard under `path` (index file optional) and return params in our fused layout; with
+    return_extra also the HF tensors the fused layout does not hold (pass them back to save_pretrained)."""
     idx = os.path.join(path, "model.safetensors.index.json")
     if os.path.exists(idx):
         files = sorted(set(json.load(open(idx))["weight_map"].values()))
@@ -57,7 +124,12 @@ def load_pretrained(cfg: LlavaConfig, path: str):
     sd = {}
     for f in files:
         sd.update(load_file(os.path.join(path, f)))
-    return from_hf_state_dict(cfg, sd, detect_hf_style(sd.keys()))
+    style = detect_hf_style(sd.keys())
+    params = from_hf_state_dict(cfg, sd, style)
+    if not return_extra:
+        return params
+    extra = OrderedDict((k, sd[k]) for k in unused_hf_tensor_shapes(cfg, style) if k in sd)
+    return params, extra
 
 
 # ------------------------------------------------------------------------------------------------ LoRA adapters

@@ -161,17 +161,21 @@ def mm_data_collator_preprocessor(samples, tok: TokenizerAdapter, max_length: in
         input_ids[i, sl] = torch.tensor(r, dtype=torch.int64)
         attn[i, sl] = 1
 
-    labels = input_ids.clone()  # mm/dataset.py:323-340
-    for n_q, lab in zip(n_questions, labels):
-        non_pad = (lab != tok.pad_token_id).nonzero(as_tuple=True)[0]
-        if len(non_pad) > 0:
-            if tok.padding_side == "left":
-                lab[: non_pad[0] + n_q] = -100
-            else:
-                lab[non_pad[0]: non_pad[0] + n_q] = -100
-                lab[non_pad[-1] + 1:] = -100
-        else:
-            lab[:] = -100
+    # Labels (mm/dataset.py:323-340), all rows at once: everything up to and including the question is ignored, counted
+    # from the first token that differs from the pad id (so a pad id that also occurs as a real token shifts the span,
+    # exactly as in the reference); right padding also ignores what follows the last non-pad token; an all-pad row is
+    # ignored entirely.
+    non_pad = input_ids != tok.pad_token_id
+    first = non_pad.to(torch.int64).argmax(dim=1, keepdim=True)
+    last = L - 1 - non_pad.flip(1).to(torch.int64).argmax(dim=1, keepdim=True)
+    t = torch.arange(L, dtype=torch.int64)[None]
+    q_end = first + torch.tensor(n_questions, dtype=torch.int64)[:, None]
+    if tok.padding_side == "left":
+        ignore = t < q_end
+    else:
+        ignore = ((t >= first) & (t < q_end)) | (t > last)
+    ignore |= ~non_pad.any(dim=1, keepdim=True)
+    labels = torch.where(ignore, torch.full_like(input_ids, -100), input_ids)
 
     out = {"input_ids": input_ids, "attention_mask": attn}
     images = [s["image"] for s in samples if s.get("image", None) is not None]

@@ -725,3 +725,21 @@ def test_compute_loss_under_hf_trainer(dev):
     assert tr.state.global_step == 2
     assert not torch.equal(before, model.train_flat.detach())
     assert torch.isfinite(model.train_flat.detach().float()).all()
+
+
+def test_forget_entry_point_end_to_end(dev, tmp_path):
+    """python -m multimodal_unlearning_amd.forget on the tiny architecture with synthetic pairs: config.yaml written, the
+    reference's step formulae, losses logged, and an HF-layout directory saved that load_pretrained reads back."""
+    from multimodal_unlearning_amd.checkpoint import load_pretrained
+    from multimodal_unlearning_amd.forget import ForgetRunConfig, parse_overrides, run
+
+    out = str(tmp_path / "run")
+    rc = parse_overrides(["model_family=tiny", f"save_dir={out}", "forget_data_path=synthetic:16", "batch_size=2",
+                          "gradient_accumulation_steps=2", "num_epochs=2", "seq_len=40", "lr=1e-3", "forget_loss=KL"],
+                         ForgetRunConfig())
+    eng = run(rc)
+    assert eng.opt_step == 2 * 16 // (2 * 2) and eng.warmup_steps == 16 // 4  # mm/forget.py:65-68,147-148
+    assert os.path.exists(os.path.join(out, "config.yaml")) and os.path.exists(os.path.join(out, "config.json"))
+    back = load_pretrained(tiny_test_config(), out)
+    assert torch.equal(back["lm_head.weight"].to(torch.bfloat16), eng.model.w["lm_head.weight"].cpu())
+    assert eng.trainer.teacher_model is not None  # KL: the frozen copy of the starting weights
