@@ -129,6 +129,17 @@ struct FragOffsets {
             tr2[dt] = r2 * (D * 2) + ((ch ^ swz<D, KIND>(r2)) << 4) + sub;
         }
     }
+    // Double-buffered tiles sit 2^k bytes apart: the offsets follow the buffer by an in-place XOR (D/16 + D/16 v_xor per
+    // block) instead of one v_add of the tile base in front of every LDS read (72 per block in the backward kernels:
+    // a quarter of their VALU instructions); everything else about an address is an instruction immediate.
+    __device__ __forceinline__ void toggle_rows(int bit) {
+#pragma unroll
+        for (int ks = 0; ks < D / 16; ++ks) row[ks] ^= bit;
+    }
+    __device__ __forceinline__ void toggle_tr(int bit) {
+#pragma unroll
+        for (int dt = 0; dt < D / 32; ++dt) { tr1[dt] ^= bit; tr2[dt] ^= bit; }
+    }
 };
 
 __device__ __forceinline__ bf16x8 tr_load(const MMU_LDS char* p1, const MMU_LDS char* p2) {
@@ -291,7 +302,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     // One KV block (64 keys).  MASKED = false is the fast path for blocks that need no causal / padding / tail mask:
     // no compares, no bias loads, and exp2(fma(s, c, -m)) instead of scale + bias + subtract.
     auto block = [&](const bool masked, int kb, int buf) {
-        const MMU_LDS char* kt = (const MMU_LDS char*)smem + buf * 2 * TB;
+        // fo_k / fo_v already point into buffer `buf` (toggled in place by the caller): tile bases are immediates
+        const MMU_LDS char* kt = (const MMU_LDS char*)smem;
         const MMU_LDS char* vt = kt + TB;
         const MMU_LDS float* kbs = (const MMU_LDS float*)(smem + 4 * TB) + buf * 64;
         f32x16 s[2];
@@ -407,6 +419,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (kb + 1 < nblk) stage(kb + 1, cur ^ 1);
+        if (kb > 0) {
+            fo_k.toggle_rows(2 * TB);
+            fo_v.toggle_tr(2 * TB);
+        }
         const bool active = !CAUSAL || (kb * 64 <= q0 + 31);
         if (active) {
             // wave-uniform: does any element of this block need a mask?
@@ -433,10 +449,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 }
 
 // delta[b][h][s] = sum_d dO[b,s,h,d] * O[b,s,h,d]: D/8 lanes per (row, head), 16-B loads, shuffle reduce
+// Also writes lse2[b][h][s] = lse * log2(e) behind delta (the workspace holds 2 * B*H*S floats): the backward kernels
+// then form p = exp2(fma(s, c, -lse2)) with one instruction per element instead of a multiply and an fma.
 template <int D>
 __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict__ o, int ldo,
                                                          const bf16* __restrict__ dout, int lddo,
-                                                         float* __restrict__ delta, int B, int S, int H) {
+                                                         float* __restrict__ delta, const float* __restrict__ lse, int B,
+                                                         int S, int H) {
     constexpr int LPG = D / 8;  // lanes per (row, head) group
     const size_t gid = ((size_t)blockIdx.x * 256 + threadIdx.x) / LPG;
     const int sub = threadIdx.x % LPG;
@@ -456,7 +475,9 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict_
     for (int off = LPG / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
     if (gid < total && sub == 0) {
         const int b = (int)(row / S), sq = (int)(row % S);
-        delta[((size_t)b * H + h) * S + sq] = acc;
+        const size_t i = ((size_t)b * H + h) * S + sq;
+        delta[i] = acc;
+        delta[total + i] = lse[i] * LOG2E;
     }
 }
 
@@ -498,7 +519,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
         }
     }
     const size_t sidx = ((size_t)b * a.H + hh) * S + (qvalid ? qrow : S - 1);
-    const float lse2 = qvalid ? a.lse[sidx] * LOG2E : INFINITY;
+    const float lse2 = qvalid ? a.delta[(size_t)a.B * a.H * S + sidx] : INFINITY;  // lse * log2(e), from the delta kernel
     const float dlt = a.delta[sidx];
     FragOffsets<D, KIND_ROW> fo;
     fo.init(lane);
@@ -529,12 +550,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (kb + 1 < nblk) stage(kb + 1, cur ^ 1);
+        if (kb > 0) {  // the fragment offsets follow the buffer (in-place XOR; tile bases are immediates below)
+            fo.toggle_rows(2 * TB);
+            fo.toggle_tr(2 * TB);
+        }
         const bool active = !CAUSAL || (kb * 64 <= q0 + 31);
         if (active) {
-            const MMU_LDS char* kt = (const MMU_LDS char*)smem + cur * 2 * TB;
+            const MMU_LDS char* kt = (const MMU_LDS char*)smem;
             const MMU_LDS char* vt = kt + TB;
             const MMU_LDS float* kbs = (const MMU_LDS float*)(smem + 4 * TB) + cur * 64;
             const bool diag = CAUSAL && (kb * 64 + 63 > q0);
+            // wave-uniform: a block below the diagonal with 64 real, unmasked keys needs no bias, compare or select
+            const bool plain = !diag && (kb * 64 + 64 <= S) && a.kmask == nullptr;
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
                 f32x16 s, dp;
@@ -558,16 +585,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                // dS^T without the 1/sqrt(D) factor: it multiplies the finished dQ accumulators once, after the sweep
+                if (plain) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int kl = st * 32 + 8 * g + 4 * hl;
-                    const f32x4 kb4 = *(const MMU_LDS f32x4*)(kbs + kl);
+                    for (int r = 0; r < 16; ++r) s[r] = fast_exp2(__builtin_fmaf(s[r], c, -lse2)) * (dp[r] - dlt);
+                } else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float x = s[4 * g + j] * c + kb4[j] - lse2;
-                        if (diag && (kb * 64 + kl + j > qrow)) x = -INFINITY;
-                        const float p = fast_exp2(x);
-                        s[4 * g + j] = p * (dp[4 * g + j] - dlt) * a.scale;
+                    for (int g = 0; g < 4; ++g) {
+                        const int kl = st * 32 + 8 * g + 4 * hl;
+                        const f32x4 kb4 = *(const MMU_LDS f32x4*)(kbs + kl);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            float x = __builtin_fmaf(s[4 * g + j], c, kb4[j] - lse2);
+                            if (diag && (kb * 64 + kl + j > qrow)) x = -INFINITY;
+                            s[4 * g + j] = fast_exp2(x) * (dp[4 * g + j] - dlt);
+                        }
                     }
                 }
 #pragma unroll
@@ -587,6 +619,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
         }
     }
     if (qvalid) {
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[dt][r] *= a.scale;
         bf16* op = a.dq + (rowbase + qrow) * a.ldg + hh * D;
         const bf16* cr = nullptr;
         const bf16* sr = nullptr;
@@ -629,7 +665,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
     const bf16* kp = a.k + rowbase * a.ld + hh * D;
     const bf16* vp = a.v + rowbase * a.ld + hh * D;
     const bf16* dop = a.dout + rowbase * a.lddo + hh * D;
-    const float* lsep = a.lse + ((size_t)b * a.H + hh) * S;
+    const float* lsep = a.delta + ((size_t)a.B * a.H + (size_t)b * a.H + hh) * S;  // lse * log2(e) (attn_delta_kernel)
     const float* dltp = a.delta + ((size_t)b * a.H + hh) * S;
     char* qd_base = smem + 2 * KVB;                                   // [2][Q | dO]
     float* rowc = reinterpret_cast<float*>(smem + 2 * KVB + 4 * TB);  // [2][lse 64 | delta 64]
@@ -637,13 +673,18 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
     const int key0 = kvb * 128 + kw * 32;
     const int key = key0 + (lane & 31);
     const bool kvalid = key < S && (a.kmask == nullptr || a.kmask[rowbase + key] != 0);
+    const bool all_valid = __all(kvalid);  // wave-uniform: tiles below the diagonal then need no select at all
 
-    // per-lane fragment offsets (bytes, relative to a tile whose fragment starts at row 0)
+    // Per-lane LDS byte offsets of this wave's Q-tile fragments inside buffer 0 (query half qh included); the dO tile
+    // (+TB), the second k-step of a transposed read (+16 rows) and the K / V tiles are instruction immediates or one
+    // wave-uniform delta away, and the double buffer is followed by an in-place XOR (see FragOffsets::toggle_rows).
+    constexpr int QOFF = 2 * KVB;  // Q/dO double buffer: 64 KiB into the LDS, buffers 32 KiB apart
     int off_row[NKS];  // row fragment, k-step ks: row (lane&31), chunk 2ks+hl
     {
         const int r = lane & 31;
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) off_row[ks] = r * (D * 2) + (((2 * ks + hl) ^ swz<D, KIND_ROW>(r)) << 4);
+        for (int ks = 0; ks < NKS; ++ks)
+            off_row[ks] = QOFF + qh * 32 * (D * 2) + r * (D * 2) + (((2 * ks + hl) ^ swz<D, KIND_ROW>(r)) << 4);
     }
     int off_tr1[NDT], off_tr2[NDT];  // transposed fragment for k-step 0 (k-step 1: + 16 rows = 16*D*2 bytes)
     {
@@ -653,8 +694,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) {
             const int ch = 4 * dt + 2 * gb + (pp >> 1);
-            off_tr1[dt] = r1 * (D * 2) + ((ch ^ swz<D, KIND_ROW>(r1)) << 4) + sub;
-            off_tr2[dt] = r2 * (D * 2) + ((ch ^ swz<D, KIND_ROW>(r2)) << 4) + sub;
+            off_tr1[dt] = QOFF + qh * 32 * (D * 2) + r1 * (D * 2) + ((ch ^ swz<D, KIND_ROW>(r1)) << 4) + sub;
+            off_tr2[dt] = QOFF + qh * 32 * (D * 2) + r2 * (D * 2) + ((ch ^ swz<D, KIND_ROW>(r2)) << 4) + sub;
         }
     }
 
@@ -687,19 +728,24 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
     stage_rows<D, KIND_ROW, 128, 8>(smem + KVB, vp, a.ld, kvb * 128, S, wave, lane);
     if (pr0 < pr1) stage(pr0, 0);
 
-    const MMU_LDS char* ktile = (const MMU_LDS char*)smem + kw * 32 * (D * 2);
-    const MMU_LDS char* vtile = ktile + KVB;
+    const MMU_LDS char* lds0 = (const MMU_LDS char*)smem;
 
     for (int pr = pr0; pr < pr1; ++pr) {
         const int cur = (pr - pr0) & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (pr + 1 < pr1) stage(pr + 1, cur ^ 1);
+        if (pr > pr0) {  // offsets follow the Q/dO buffer
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) off_row[ks] ^= 2 * TB;
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) { off_tr1[dt] ^= 2 * TB; off_tr2[dt] ^= 2 * TB; }
+        }
         const int q_first = pr * 64 + qh * 32;  // first query row of this wave's tile
         const bool active = q_first < S && (!CAUSAL || (q_first + 31 >= key0));
         if (active) {
-            const MMU_LDS char* qtile = (const MMU_LDS char*)qd_base + cur * 2 * TB + qh * 32 * (D * 2);
-            const MMU_LDS char* dotile = qtile + TB;
+            // K tile rows of this wave = the Q offsets shifted by a wave-uniform amount (one scalar per iteration)
+            const int kdelta = kw * 32 * (D * 2) - (QOFF + qh * 32 * (D * 2) + cur * 2 * TB);
             const MMU_LDS float* rc = (const MMU_LDS float*)(smem + 2 * KVB + 4 * TB) + cur * 128 + qh * 32;
             f32x16 s, dp;
 #pragma unroll
@@ -711,8 +757,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
                 bf16x8 fa[4], fb[4];
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
-                    fa[ks] = *(const MMU_LDS bf16x8*)(qtile + off_row[h4 + ks]);
-                    fb[ks] = *(const MMU_LDS bf16x8*)(ktile + off_row[h4 + ks]);
+                    fa[ks] = *(const MMU_LDS bf16x8*)(lds0 + off_row[h4 + ks]);
+                    fb[ks] = *(const MMU_LDS bf16x8*)(lds0 + (off_row[h4 + ks] + kdelta));
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -724,28 +770,44 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
                 bf16x8 fa[4], fb[4];
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
-                    fa[ks] = *(const MMU_LDS bf16x8*)(dotile + off_row[h4 + ks]);
-                    fb[ks] = *(const MMU_LDS bf16x8*)(vtile + off_row[h4 + ks]);
+                    fa[ks] = *(const MMU_LDS bf16x8*)(lds0 + off_row[h4 + ks] + TB);
+                    fb[ks] = *(const MMU_LDS bf16x8*)(lds0 + (off_row[h4 + ks] + kdelta) + KVB);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks], fb[ks], dp, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            // P and dS (without the 1/sqrt(D) factor: it multiplies the finished dK accumulators once, after the sweep)
             const bool diag = CAUSAL && (q_first < key0 + 31);
+            if (all_valid && !diag) {  // wave-uniform: no select
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int ql = 8 * g + 4 * hl;  // local q row of reg 4g
-                const f32x4 l4 = *(const MMU_LDS f32x4*)(rc + ql);
-                const f32x4 d4 = *(const MMU_LDS f32x4*)(rc + 64 + ql);
+                for (int g = 0; g < 4; ++g) {
+                    const int ql = 8 * g + 4 * hl;  // local q row of reg 4g
+                    const f32x4 l4 = *(const MMU_LDS f32x4*)(rc + ql);
+                    const f32x4 d4 = *(const MMU_LDS f32x4*)(rc + 64 + ql);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float x = s[4 * g + j] * c - l4[j] * LOG2E;
-                    bool ok = kvalid;
-                    if (diag && (key > q_first + ql + j)) ok = false;
-                    const float p = ok ? fast_exp2(x) : 0.f;
-                    s[4 * g + j] = p;
-                    dp[4 * g + j] = p * (dp[4 * g + j] - d4[j]) * a.scale;
+                    for (int j = 0; j < 4; ++j) {
+                        const float pv = fast_exp2(__builtin_fmaf(s[4 * g + j], c, -l4[j]));
+                        s[4 * g + j] = pv;
+                        dp[4 * g + j] = pv * (dp[4 * g + j] - d4[j]);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int ql = 8 * g + 4 * hl;
+                    const f32x4 l4 = *(const MMU_LDS f32x4*)(rc + ql);
+                    const f32x4 d4 = *(const MMU_LDS f32x4*)(rc + 64 + ql);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float x = __builtin_fmaf(s[4 * g + j], c, -l4[j]);
+                        bool ok = kvalid;
+                        if (diag && (key > q_first + ql + j)) ok = false;
+                        const float pv = ok ? fast_exp2(x) : 0.f;
+                        s[4 * g + j] = pv;
+                        dp[4 * g + j] = pv * (dp[4 * g + j] - d4[j]);
+                    }
                 }
             }
             // dV^T[d][key] += dO^T[d][q] P[q][key] ; dK^T[d][key] += Q^T[d][q] dS[q][key]
@@ -757,14 +819,14 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
 #pragma unroll
                 for (int dt = 0; dt < NDT; ++dt) {
                     const bf16x4 o1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                        (MMU_LDS bf16x4*)(dotile + off_tr1[dt] + sk * 16 * D * 2));
+                        (MMU_LDS bf16x4*)(lds0 + off_tr1[dt] + TB + sk * 16 * D * 2));
                     const bf16x4 o2 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                        (MMU_LDS bf16x4*)(dotile + off_tr2[dt] + sk * 16 * D * 2));
+                        (MMU_LDS bf16x4*)(lds0 + off_tr2[dt] + TB + sk * 16 * D * 2));
                     fo[dt] = __builtin_shufflevector(o1, o2, 0, 1, 2, 3, 4, 5, 6, 7);
                     const bf16x4 q1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                        (MMU_LDS bf16x4*)(qtile + off_tr1[dt] + sk * 16 * D * 2));
+                        (MMU_LDS bf16x4*)(lds0 + off_tr1[dt] + sk * 16 * D * 2));
                     const bf16x4 q2 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                        (MMU_LDS bf16x4*)(qtile + off_tr2[dt] + sk * 16 * D * 2));
+                        (MMU_LDS bf16x4*)(lds0 + off_tr2[dt] + sk * 16 * D * 2));
                     fq[dt] = __builtin_shufflevector(q1, q2, 0, 1, 2, 3, 4, 5, 6, 7);
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -797,7 +859,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
         for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                dk[dt][r] += slab[(dt * 16 + r) * 64 + lane];
+                dk[dt][r] = (dk[dt][r] + slab[(dt * 16 + r) * 64 + lane]) * a.scale;
                 dv[dt][r] += slab[(64 + dt * 16 + r) * 64 + lane];
             }
         const bf16* cr = nullptr;
@@ -847,7 +909,7 @@ int launch_bwd(const AttnArgs& a, hipStream_t s) {
     }
     const size_t nthr = (size_t)a.B * a.S * a.H * (D / 8);
     hipLaunchKernelGGL((attn_delta_kernel<D>), dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, a.o, a.ldo, a.dout,
-                       a.lddo, const_cast<float*>(a.delta), a.B, a.S, a.H);
+                       a.lddo, const_cast<float*>(a.delta), a.lse, a.B, a.S, a.H);
     MMU_CHECK_LAUNCH();
     hipLaunchKernelGGL((attn_bwd_dkdv_kernel<D, CAUSAL>), dim3(((a.S + 127) / 128) * a.H * a.B), dim3(512), LDS_KV, s, a);
     MMU_CHECK_LAUNCH();

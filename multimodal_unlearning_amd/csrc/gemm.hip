@@ -431,7 +431,7 @@ __device__ __forceinline__ void decode_tile(const GemmArgs& p, int vt, int& m0, 
 
 // Reduce the split-K partial accumulators of remainder tile r = blockIdx.x: C (+)= sum of its sk_split fp32 partials.  Workspace slot layout = the accumulator layout of the GEMM kernel:
 // [fragment (a,mt,b,nt)][wave][lane][4 consecutive columns].
-__global__ __launch_bounds__(256) void sk_fold_kernel(GemmArgs p, int accumulate) {
+__global__ __launch_bounds__(256) void sk_fold_kernel(GemmArgs p, int epi) {
     const int r = blockIdx.x;
     const int nk = (p.K + 63) / 64;
     const int kc = (nk + p.sk_split - 1) / p.sk_split;
@@ -451,17 +451,11 @@ __global__ __launch_bounds__(256) void sk_fold_kernel(GemmArgs p, int accumulate
         const int wm = wave >> 2, wn = wave & 3;
         const int m = m0 + wm * 128 + a * 64 + mt * 16 + (lane & 15);
         const int n = n0 + (wn >> 1) * 128 + b * 64 + (wn & 1) * 32 + nt * 16 + 4 * (lane >> 4);
-        if (m >= p.M || n >= p.N) continue;
-        bf16* cp = p.C + (size_t)m * p.ldc + n;
-        if (accumulate) {
-            const bf16x4 cv = *reinterpret_cast<const bf16x4*>(cp);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) sum[j] += bf2f(cv[j]);
-        }
-        bf16x4 out;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) out[j] = f2bf(sum[j]);
-        *reinterpret_cast<bf16x4*>(cp) = out;
+        // the GEMM kernel's own epilogue on the summed tile: 0 plain, 1 bias / activation / residual (HF rounding
+        // points), 2 accumulate into C
+        if (epi == 1) epi_store<1>(p, m, n, sum);
+        else if (epi == 2) epi_store<2>(p, m, n, sum);
+        else epi_store<0>(p, m, n, sum);
     }
 }
 
@@ -751,14 +745,16 @@ int launch_epi(GemmArgs a, hipStream_t stream) {
     const int tiles = a.tiles_m * a.tiles_n;
     // Split-K tail: with T tiles on 256 CUs the last T % 256 tiles occupy a whole round; when they are at most half a
     // round, cut each into S = 256 / rem K ranges over rem * S extra workgroups (gate_up wgrad: 96 tiles x 2 ranges
-    // = 5.5 rounds instead of 6).  Plain / accumulate epilogues only (the fold kernel applies neither bias,
-    // activation, residual nor RoPE).
+    // = 5.5 rounds instead of 6).  The fold kernel applies the tile's epilogue (plain, bias / activation / residual
+    // with the HF rounding points, or accumulate) to the summed partials; only the fused-RoPE epilogue is never split.
+    // With the reference's default micro-batch (2 pairs = 4352 tokens = 17 tile rows) the o / down projections are
+    // 272 tiles = 1.06 rounds: their 16 remainder tiles become 128 K-range workers instead of a second round.
     const int rem = tiles % g_num_cu;
     const int nk = (a.K + 63) / 64;
     int split = rem ? g_num_cu / rem : 0;
     if (split > 8) split = 8;
     if (split > nk) split = nk;
-    bool sk = g_tail_split && split >= 2 && EPI != 1 && !a.rope_pos && g_sk_ws &&
+    bool sk = g_tail_split && split >= 2 && !a.rope_pos && g_sk_ws &&
               g_sk_ws_bytes >= (size_t)g_num_cu * 65536 * sizeof(float);
     if (sk && g_tail_split == 1) {
         const double saving_us = (1.0 - 1.0 / split) * nk * 1.45;  // measured us per K-tile of one tile
@@ -772,7 +768,7 @@ int launch_epi(GemmArgs a, hipStream_t stream) {
         a.sk_ws = g_sk_ws;
         hipLaunchKernelGGL(kern, dim3(a.sk_first + rem * split), dim3(512), LDS_BYTES, stream, a);
         MMU_CHECK_LAUNCH();
-        hipLaunchKernelGGL(sk_fold_kernel, dim3(rem, 8), dim3(256), 0, stream, a, EPI == 2 ? 1 : 0);
+        hipLaunchKernelGGL(sk_fold_kernel, dim3(rem, 8), dim3(256), 0, stream, a, EPI);
         MMU_CHECK_LAUNCH();
         return 0;
     }

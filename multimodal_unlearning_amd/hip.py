@@ -247,9 +247,11 @@ def attn_fwd(q, k, v, out, lse, kmask, B, S, H, head_dim, scale, causal):
 
 
 def attn_bwd(q, k, v, o, lse, kmask, dout, delta, dq, dk, dv, B, S, H, head_dim, scale, causal, rope=None):
-    """rope = (pos_ids int32 [B*S], cos_t, sin_t [n_pos,64]): fuse the inverse RoPE rotation into the dq / dk stores."""
+    """rope = (pos_ids int32 [B*S], cos_t, sin_t [n_pos,64]): fuse the inverse RoPE rotation into the dq / dk stores.
+    delta: fp32 workspace of 2 * B * H * S floats (delta, then lse * log2 e)."""
     _bf16c(q, k, v, o, dout, dq, dk, dv)
     assert dq.stride(0) == dk.stride(0) == dv.stride(0)
+    assert delta.dtype == torch.float32 and delta.is_contiguous() and delta.numel() >= 2 * B * S * H
     pos, ct, st = rope if rope is not None else (None, None, None)
     rc = load().mmu_attn_bwd_rope(_p(q), _p(k), _p(v), q.stride(0), _p(o), o.stride(0), _p(lse), _p(kmask), _p(dout),
                                   dout.stride(0), _p(delta), _p(dq), _p(dk), _p(dv), dq.stride(0), B, S, H, head_dim,

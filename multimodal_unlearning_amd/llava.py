@@ -692,7 +692,7 @@ class LlavaHIP(nn.Module):
         dh.view(n, T, dv)[:, 1:].copy_(dfeats.view(n, T - 1, dv))  # the CLS row feeds nothing downstream
         scale = D ** -0.5
         pad = lambda src: hip.head_pad(src, D, torch.empty(M, H * 128, device=dev, dtype=BF), 128, H)
-        delta = torch.empty(n, H, T, device=dev, dtype=torch.float32)
+        delta = torch.empty(2, n, H, T, device=dev, dtype=torch.float32)
         for i in reversed(range(len(clip_saved))):
             p = f"vision.layers.{i}."
             h, y1, qkv, a, lse, h2, y2, z, za = clip_saved[i]
@@ -853,7 +853,7 @@ class LlavaHIP(nn.Module):
             above = [self.range_of(n) for n in self._toff if self._is_above(n, top)]
             if above:
                 hook(min(a for a, _ in above), max(b for _, b in above))
-        delta = torch.empty(B, H, S, device=dev, dtype=torch.float32)
+        delta = torch.empty(2, B, H, S, device=dev, dtype=torch.float32)
         layers = saved["layers"]
         for i in reversed(range(top + 1)):
             p = f"text.layers.{i}."

@@ -210,7 +210,7 @@ def test_attn_bwd(dev, B, H, S, causal, pad):
     hip.attn_fwd(qkv[:, :HD], qkv[:, HD:2 * HD], qkv[:, 2 * HD:], out, lse, kmask, B, S, H, D, scale, causal)
     dout = dof.to(BF).permute(0, 2, 1, 3).reshape(B * S, HD).contiguous()
     dqkv = torch.full((B * S, 3 * HD), 9.0, device=dev, dtype=BF)
-    delta = torch.empty(B, H, S, device=dev, dtype=torch.float32)
+    delta = torch.empty(2, B, H, S, device=dev, dtype=torch.float32)
     hip.attn_bwd(qkv[:, :HD], qkv[:, HD:2 * HD], qkv[:, 2 * HD:], out, lse, kmask, dout, delta, dqkv[:, :HD],
                  dqkv[:, HD:2 * HD], dqkv[:, 2 * HD:], B, S, H, D, scale, causal)
     torch.cuda.synchronize()
@@ -575,7 +575,7 @@ def test_fused_rope_epilogue_and_bwd_store(dev):
     sc = 1 / math.sqrt(D)
     hip.attn_fwd(qkv[:, :dt], qkv[:, dt:2 * dt], qkv[:, 2 * dt:], o, lse, None, B, S, H, D, sc, True)
     do = _randn((M, dt), dev, 1.0, 3)
-    delta = torch.empty(B, H, S, device=dev, dtype=torch.float32)
+    delta = torch.empty(2, B, H, S, device=dev, dtype=torch.float32)
     d1 = torch.empty(M, 3 * dt, device=dev, dtype=BF)
     hip.attn_bwd(qkv[:, :dt], qkv[:, dt:2 * dt], qkv[:, 2 * dt:], o, lse, None, do, delta, d1[:, :dt], d1[:, dt:2 * dt],
                  d1[:, 2 * dt:], B, S, H, D, sc, True)
@@ -677,6 +677,7 @@ def test_gemm256_split_tail_matches(dev, layout, shape):
     c_init = _rand_int((M, N), dev, -3, 3, seed=23)
     U = _rand_int((M, 32), dev, -1, 1, seed=24)
     BL = _rand_int((N, 32), dev, -1, 1, seed=25)
+    bias = _rand_int((N,), dev, -2, 2, seed=26)
     hip.gemm_set_tile(256)
     try:
         res = []
@@ -688,13 +689,18 @@ def test_gemm256_split_tail_matches(dev, layout, shape):
             hip.gemm(layout, A, Bm, c1, accumulate=True)
             c2 = torch.empty(M, N, device=dev, dtype=BF)
             hip.gemm(layout, A, Bm, c2, lora_u=U, lora_b=BL)
-            res.append((c0, c1, c2))
+            c3 = torch.empty(M, N, device=dev, dtype=BF)  # bias + residual epilogue (o / down projections: round 2)
+            hip.gemm(layout, A, Bm, c3, bias=bias, resid=c_init)
+            c4 = torch.empty(M, N, device=dev, dtype=BF)
+            hip.gemm(layout, A, Bm, c4, bias=bias, act=hip.ACT_QUICK_GELU)
+            res.append((c0, c1, c2, c3, c4))
         for x, y in zip(*res):
             assert torch.equal(x, y)
         ref = a.float() @ b.float().t()
         assert torch.equal(res[1][0], ref.to(BF))
         assert torch.equal(res[1][1], (ref + c_init.float()).to(BF))
         assert torch.equal(res[1][2], (ref + U.float() @ BL.float().t()).to(BF))
+        assert torch.equal(res[1][3], ((ref + bias.float()).to(BF).float() + c_init.float()).to(BF))
     finally:
         hip.gemm_set_tail_split(1)
         hip.gemm_set_tile(0)

@@ -13,7 +13,7 @@ o = torch.empty(B * S, HD, device=dev, dtype=torch.bfloat16)
 lse = torch.empty(B, H, S, device=dev, dtype=torch.float32)
 do = torch.randn(B * S, HD, device=dev, generator=g).bfloat16()
 dqkv = torch.empty_like(qkv)
-delta = torch.empty(B, H, S, device=dev, dtype=torch.float32)
+delta = torch.empty(2, B, H, S, device=dev, dtype=torch.float32)
 sc = 1 / math.sqrt(D)
 def fwd(): hip.attn_fwd(qkv[:, :HD], qkv[:, HD:2*HD], qkv[:, 2*HD:], o, lse, None, B, S, H, D, sc, True)
 def bwd(): hip.attn_bwd(qkv[:, :HD], qkv[:, HD:2*HD], qkv[:, 2*HD:], o, lse, None, do, delta, dqkv[:, :HD], dqkv[:, HD:2*HD], dqkv[:, 2*HD:], B, S, H, D, sc, True)
