@@ -124,7 +124,7 @@ class GemmTimer:
                                                      "avg_us": round(v[2] / v[0] * 1e6, 1)} for k, v in by.items()}
 
 
-def cpu_baseline(cfg, S, budget_layers=1, clip_layers=2):
+def cpu_baseline(cfg, S, budget_layers=4, clip_layers=4):
     """Oracle (bf16 CPU restatement of the reference path) on the host cores: full-width model cut to
     `budget_layers` decoder layers and `clip_layers` CLIP layers, one forget+retain pair at B=1, fwd+bwd of
     grad_diff; the per-layer terms are extrapolated linearly to the full depth."""
@@ -168,9 +168,9 @@ def cpu_baseline(cfg, S, budget_layers=1, clip_layers=2):
         return time.perf_counter() - t0
 
     run(0, 1)  # warm-up (allocator, thread pool)
+    t_clip1 = run(0, 1)
     t_base = run(0, clip_layers)             # embeddings + CLIP(clip_layers) + projector + lm_head + loss
     t_full = run(budget_layers, clip_layers)  # + budget_layers decoder layers
-    t_clip1 = run(0, 1)
     per_dec = max(1e-6, (t_full - t_base) / budget_layers)
     per_clip = max(0.0, (t_base - t_clip1) / max(1, clip_layers - 1))
     est = t_base + per_dec * cfg.text.num_layers + per_clip * (cfg.vision_layers_used - clip_layers)
@@ -266,6 +266,8 @@ def main():
     ap.add_argument("--loss", default="grad_diff_forget_ce_retain_ce")
     ap.add_argument("--layers", type=int, default=0, help="debug: override decoder depth (invalidates the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-reference-batch", action="store_true",
+                    help="skip the extra 4 steps at the reference's default micro-batch (2 pairs) after the timed region")
     ap.add_argument("--gemm-group-m", type=int, default=None, help="A/B: GROUP_M rasterisation of the 256^2 GEMM (default 4)")
     ap.add_argument("--gemm-persist", type=int, default=None, help="A/B: 256^2 GEMM launch mode (0 workgroup per tile, 1 persistent = default)")
     ap.add_argument("--gemm-tail-split", type=int, default=None, help="A/B: split-K tail of the 256^2 GEMM (0 off, 1 heuristic = default)")
@@ -395,6 +397,20 @@ def main():
     rank_exch_ms = [float(t[1]) for t in per_rank]
     elapsed = max(rank_elapsed)
 
+    # The same step at the REFERENCE's default per-device batch (2 pairs x GA 4, config/mm/forget.yaml:14-15) on the same
+    # model / optimiser state, reported beside the headline (whose micro-batch is sized for 288 GB): 1 warm-up + 3 steps.
+    ref_batch = None
+    if world == 1 and not args.text_only and args.model != "tiny" and B != 2 and not args.no_reference_batch:
+        rb = [bench_batch(cfg, 2, seed=4321 + i, splits=splits, device=dev) for i in range(GA)]
+        eng.step(rb)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            eng.step(rb)
+        torch.cuda.synchronize()
+        ref_batch = 3 * 2 * GA / (time.perf_counter() - t1)
+        del rb
+
     if rank == 0:
         samples = world * B * GA * args.steps
         value = samples / elapsed
@@ -442,6 +458,10 @@ def main():
                        "optimizer": ("AdamW fp32 moments" if args.optim == "adamw" else "AdamW block-wise 8-bit moments") + ", clip 1.0",
                        "lora_r": args.lora_r,
                        "keep_act_t": model.keep_act_t,
+                       "reference_batch_value": (None if ref_batch is None else
+                                                 {"micro_batch_pairs_per_gpu": 2, "grad_accum": GA,
+                                                  "samples_per_s": round(ref_batch, 4),
+                                                  "step_frac_of_mfma_peak": round(ref_batch * fps / PEAK_BF16, 4)}),
                        "decoder_layers": cfg.text.num_layers},
             "per_rank_samples_per_s": [round(B * GA * args.steps / t_, 4) for t_ in rank_elapsed],
             "dp": {"mode": args.dp_mode if world > 1 else None, "backend": (dist.get_backend() if world > 1 else None),

@@ -459,12 +459,19 @@ __global__ __launch_bounds__(256) void sk_fold_kernel(GemmArgs p, int epi) {
     }
 }
 
+#ifdef MMU_CLOCK_STAMP
+__device__ unsigned long long g_clock_stamps[2 * 1024];
+#endif
+
 template <bool AT, bool BT, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave >> 2, wn = wave & 3;
+#ifdef MMU_CLOCK_STAMP  // diagnostic build only (tools/gemm_clock.py): shader clock held under this load
+    const unsigned long long stamp_t0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     const int total_tiles = p.tiles_m * p.tiles_n;
     const int nk = (p.K + 63) / 64;
@@ -719,6 +726,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     if (!more) break;
     G256_PROLOGUE();
   }
+#ifdef MMU_CLOCK_STAMP
+    // the stamps leave through a buffer of their own that nothing else reads; no output depends on them
+    if (threadIdx.x == 0 && blockIdx.x < 1024) {
+        g_clock_stamps[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - stamp_t0;          // shader cycles
+        g_clock_stamps[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - stamp_r0;  // 100 MHz ticks
+    }
+#endif
 #undef G256_PROLOGUE
 #undef G256_BAR
 #undef G256_LGKM8
@@ -754,9 +768,9 @@ int launch_epi(GemmArgs a, hipStream_t stream) {
     int split = rem ? g_num_cu / rem : 0;
     if (split > 8) split = 8;
     if (split > nk) split = nk;
-    bool sk = g_tail_split && split >= 2 && !a.rope_pos && g_sk_ws &&
+    bool sk = g_tail_split && split >= 2 && !a.rope_pos && !(g_tail_split == 3 && EPI == 1) && g_sk_ws &&
               g_sk_ws_bytes >= (size_t)g_num_cu * 65536 * sizeof(float);
-    if (sk && g_tail_split == 1) {
+    if (sk && g_tail_split != 2) {
         const double saving_us = (1.0 - 1.0 / split) * nk * 1.45;  // measured us per K-tile of one tile
         const double cost_us = 15.0 + 0.1 * rem * split;           // partial write + fold read at ~5 TB/s
         sk = saving_us > 1.5 * cost_us;
@@ -950,7 +964,7 @@ extern "C" int mmu_gemm_set_persistent(int mode) {
 // (default), 2 whenever the remainder tiles fill at most half a round (tests).  It needs a device workspace of at
 // least 256 * 256 KiB = 64 MiB registered with mmu_gemm_set_workspace (the library never allocates).
 extern "C" int mmu_gemm_set_tail_split(int mode) {
-    if (mode < 0 || mode > 2) return -1;
+    if (mode < 0 || mode > 3) return -1;  // 3: heuristic without the bias / residual epilogue (round-1 behaviour, A/B)
     g_tail_split = mode;
     return 0;
 }
@@ -961,3 +975,11 @@ extern "C" int mmu_gemm_set_workspace(void* ws, long long bytes) {
     return 0;
 }
 extern "C" long long mmu_gemm_workspace_bytes(void) { return (long long)g_num_cu * 65536 * sizeof(float); }
+
+#ifdef MMU_CLOCK_STAMP
+// Diagnostic build only: copy the per-workgroup {shader cycles, 100 MHz ticks} of the LAST 256^2 launch to the host.
+extern "C" int mmu_debug_read_clock_stamps(unsigned long long* host_out, int n_pairs) {
+    if (n_pairs < 1 || n_pairs > 1024) return -1;
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g256::g_clock_stamps), (size_t)n_pairs * 16, 0, hipMemcpyDeviceToHost);
+}
+#endif

@@ -21,13 +21,14 @@ def _free_port():
     return p
 
 
-def _build(dev, lora=False, loss="grad_diff_forget_ce_retain_ce", loss_args=None):
+def _build(dev, lora=False, loss="grad_diff_forget_ce_retain_ce", loss_args=None, dp_mode="allreduce"):
     from multimodal_unlearning_amd.config import ForgetConfig, tiny_test_config
     from multimodal_unlearning_amd.engine import ForgetEngine
     from multimodal_unlearning_amd.llava import LlavaHIP
     from multimodal_unlearning_amd.params import init_params
     from multimodal_unlearning_amd.trainer import MMTrainerForgetting
 
+    torch.manual_seed(0)  # rmu draws its control vector with torch.rand: the same on every rank, as under set_seed
     cfg = tiny_test_config()
     if lora:
         from multimodal_unlearning_amd.llava import LoraSpec
@@ -37,64 +38,82 @@ def _build(dev, lora=False, loss="grad_diff_forget_ce_retain_ce", loss_args=None
     else:
         model = LlavaHIP(cfg, init_params(cfg, seed=0), device=dev)
     teacher = None
-    if loss in ("kl", "dpo"):
+    if loss in ("kl", "dpo", "scrub", "llmu", "rmu", "sku"):
         from multimodal_unlearning_amd.synthetic import teacher_params_from
 
         teacher = LlavaHIP(cfg, teacher_params_from(init_params(cfg, seed=0), seed=7), device=dev, trainable=False)
     tr = MMTrainerForgetting(model=model, forget_loss=loss, teacher_model=teacher, loss_beta=1.0,
                              l1_lambda=0.0, l0_lambda=0.0, l_norm_from="zero", loss_args=loss_args or {})
-    eng = ForgetEngine(model, tr, ForgetConfig(lr=1e-3), total_steps=10, warmup_steps=1)
+    # small buckets: several collectives per step on the tiny model (the flat gradient has ~0.5 M elements)
+    eng = ForgetEngine(model, tr, ForgetConfig(lr=1e-3), total_steps=10, warmup_steps=1, dp_mode=dp_mode,
+                       bucket_elems=1 << 16)
     return cfg, model, eng
 
 
-def _worker(rank, world, port, q, lora, loss, loss_args):
+SPLITS = ("forget", "retain", "idk")
+
+
+def _batch(cfg, seed, loss):
+    from multimodal_unlearning_amd.synthetic import make_forget_batch, make_split
+
+    mb = make_forget_batch(cfg, 2, 40, seed=seed, n_question=6, splits=SPLITS)
+    if loss == "sku":  # nested [B, K, ...] "random" split (mm/dataset.py:265-276)
+        ks = [make_split(cfg, 2, 40, seed=seed * 7 + k, n_question=6) for k in range(3)]
+        mb["random"] = {k: torch.stack([x[k] for x in ks], dim=1) for k in ks[0]}
+    return mb
+
+
+def _worker(rank, world, port, q, lora, loss, loss_args, dp_mode):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from multimodal_unlearning_amd.synthetic import make_forget_batch
-
-        cfg, model, eng = _build("cuda:0", lora, loss, loss_args)
-        assert eng.reducer.enabled and eng.world == 2
+        cfg, model, eng = _build("cuda:0", lora, loss, loss_args, dp_mode)
+        assert eng.reducer.enabled and eng.world == world and len(eng.reducer.buckets) > 2
         for step in range(2):
-            mb = make_forget_batch(cfg, 2, 40, seed=50 + 10 * step + rank, n_question=6, splits=SPLITS)
-            eng.step([mb])
+            eng.step([_batch(cfg, 50 + 10 * step + rank, loss)])
         torch.cuda.synchronize()
         q.put((rank, model.train_flat.detach().float().cpu().numpy()))  # numpy: no fd passing after exit
     finally:
         dist.destroy_process_group()
 
 
-SPLITS = ("forget", "retain", "idk")
+SKU = {"bad_weight": 2.5, "random_weight": 1.0, "normal_weight": 0.5}
 
 
-@pytest.mark.parametrize("lora,loss,loss_args", [
-    (False, "grad_diff_forget_ce_retain_ce", None),                  # paired fusion: one backward sweep
-    (True, "grad_diff_forget_ce_retain_ce", None),                   # adapters incl. the CLIP tower's
-    (False, "grad_diff_forget_ce_retain_ce", {"fuse_pairs": False}),  # two sweeps in one loss.backward()
-    (False, "kl", None),                                             # two student sweeps + a frozen teacher
-    (False, "dpo", None),                                            # a forward that never sweeps (reference quirk)
+@pytest.mark.parametrize("world,lora,loss,loss_args,dp_mode", [
+    (2, False, "grad_diff_forget_ce_retain_ce", None, "allreduce"),                  # paired fusion: one backward sweep
+    (2, True, "grad_diff_forget_ce_retain_ce", None, "allreduce"),                   # adapters incl. the CLIP tower's
+    (2, False, "grad_diff_forget_ce_retain_ce", {"fuse_pairs": False}, "allreduce"),  # two sweeps in one loss.backward()
+    (2, False, "kl", None, "allreduce"),                                             # two student sweeps + a frozen teacher
+    (2, False, "dpo", None, "allreduce"),                                            # a forward that never sweeps (reference quirk)
+    (2, False, "scrub", None, "allreduce"),                                          # 2 student + 2 teacher forwards
+    (2, False, "llmu", None, "allreduce"),                                           # 3 student sweeps
+    (2, False, "sku", SKU, "allreduce"),                                             # 1 + K + 1 student sweeps
+    (2, False, "rmu", {"rmu_layer": 0}, "allreduce"),                                # sweeps that stop at the hooked layer
+    (3, False, "grad_diff_forget_ce_retain_ce", {"fuse_pairs": False}, "allreduce"),  # 3 ranks, > 2 buckets in flight
+    (2, False, "grad_diff_forget_ce_retain_ce", None, "rs_ag"),                      # reduce-scatter + sharded AdamW + all-gather
+    (3, False, "kl", None, "rs_ag"),
 ])
-def test_two_ranks_match_gradient_accumulation(lora, loss, loss_args):
+def test_ranks_match_gradient_accumulation(world, lora, loss, loss_args, dp_mode):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    ps = [ctx.Process(target=_worker, args=(r, 2, port, q, lora, loss, loss_args)) for r in range(2)]
+    ps = [ctx.Process(target=_worker, args=(r, world, port, q, lora, loss, loss_args, dp_mode)) for r in range(world)]
     for p in ps:
         p.start()
     res = {r: torch.from_numpy(a) for r, a in (q.get(timeout=300) for _ in ps)}
     for p in ps:
         p.join(120)
         assert p.exitcode == 0
-    assert torch.equal(res[0], res[1])  # replicas stay identical
-    from multimodal_unlearning_amd.synthetic import make_forget_batch
-
+    for r in range(1, world):
+        assert torch.equal(res[0], res[r])  # replicas stay identical
     cfg, model, eng = _build("cuda:0", lora, loss, loss_args)
     for step in range(2):
-        eng.step([make_forget_batch(cfg, 2, 40, seed=50 + 10 * step + r, n_question=6, splits=SPLITS) for r in range(2)])
+        eng.step([_batch(cfg, 50 + 10 * step + r, loss) for r in range(world)])
     torch.cuda.synchronize()
     ref = model.train_flat.detach().float().cpu()
     err = (res[0] - ref).norm() / ref.norm()
     moved = (ref - _build("cuda:0", lora, loss, loss_args)[1].train_flat.detach().float().cpu()).norm() / ref.norm()
-    # bf16 gradients: rank-sum then 1/2 vs accumulate-of-halves differ in rounding only
+    # bf16 gradients: rank-sum then 1/world vs accumulate-of-fractions differ in rounding only
     assert moved > 1e-3 and err < 0.05 * moved, (float(err), float(moved))

@@ -9,7 +9,11 @@ kernel configuration is compared against it:
   logits  relative L2 < 1e-2 — or, where the reference's OWN bf16 path (the oracle run in bf16 = transformers' bf16
           CPU arithmetic, every module output rounded) is itself further than that from fp32 on these inputs, no
           further than 1.1x that distance (measured at 7B width, one layer, S 1088: HF-bf16 1.13e-2, HIP 1.04e-2)
-  loss    |d| < 1e-3 * max(1, |loss|)        every gradient tensor  relative L2 < 3e-2
+  loss    |d| < 1e-3 * max(1, sum of |CE terms|): grad_diff / KL are DIFFERENCES of cross-entropies of ~10.4 each
+          (random-init weights, V 32064), so the bound is 1e-3 relative to the terms the loss is made of; measured
+          |d| 2e-4 .. 2e-3 across kernel configurations (configurations differ from each other by as much: fp32
+          partial sums folded in another order change bf16 roundings of the residual stream)
+  every gradient tensor  relative L2 < 3e-2
 Reference arithmetic: /root/reference/mm/trainer.py:180-229,259-277 (`model(**inputs)`, grad_diff / KL branches) and,
 for the text trainer + LoRA case (BASELINE config 1), /root/reference/nlp/dataloader.py:144-200.
 """
@@ -50,6 +54,8 @@ def _oracle(cfg, P, Pt, loss_type, inputs):
     def student(x):
         out = llava_forward(cfg, Pf, **x)
         last["logits"], last["inputs"] = out["logits"].detach(), x
+        if out["loss"] is not None:
+            last["scale"] = last.get("scale", 0.0) + abs(float(out["loss"]))
         return out
 
     teacher = (lambda x: llava_forward(cfg, Pt, **x)) if Pt is not None else None
@@ -62,7 +68,7 @@ def _oracle(cfg, P, Pt, loss_type, inputs):
         lb = llava_forward(cfg, Pb, **last["inputs"], dtype=torch.bfloat16)["logits"].float()
     valid = last["inputs"]["attention_mask"].bool()
     e_bf16 = _relerr(lb[valid], last["logits"][valid])
-    return float(loss.detach()), last["logits"], grads, e_bf16
+    return float(loss.detach()), last["logits"], grads, e_bf16, last.get("scale", 0.0)
 
 
 # kernel configurations: (name, dict of switches)
@@ -109,8 +115,8 @@ def _run_hip(dev, cfg, P, Pt, loss_type, inputs, sw, lora=None):
 
 def _check(tag, got, ref):
     loss, logits, grads = got
-    rloss, rlogits, rgrads, e_bf16 = ref
-    assert abs(loss - rloss) < 1e-3 * max(1.0, abs(rloss)), (tag, loss, rloss)
+    rloss, rlogits, rgrads, e_bf16, scale = ref
+    assert abs(loss - rloss) < 1e-3 * max(1.0, abs(rloss), scale), (tag, loss, rloss, scale)
     el = _relerr(logits.reshape(rlogits.shape), rlogits)
     assert el < max(1e-2, 1.1 * e_bf16), (tag, "logits", el, "HF-bf16 path", e_bf16)
     worst = ("", 0.0)
@@ -168,7 +174,7 @@ def test_kl_full_width_vs_oracle(dev, width):
     for name, sw in CONFIGS[:2]:
         loss, logits, grads = _run_hip(dev, cfg, P, Pt, "KL", inputs, sw)
         # padded positions hold unspecified logits on both sides (HF gives them finite garbage too): compare valid rows
-        w = _check(f"{width}/{name}", (loss, logits[valid], grads), (ref[0], ref[1][valid], ref[2], ref[3]))
+        w = _check(f"{width}/{name}", (loss, logits[valid], grads), (ref[0], ref[1][valid], ref[2], ref[3], ref[4]))
         print(f"[fullwidth {width} KL {name}] loss {loss:+.5f} vs {ref[0]:+.5f}; logits {w[2]:.2e} (HF-bf16 {w[3]:.2e}); "
               f"worst grad {w[0]} {w[1]:.2e}")
 
