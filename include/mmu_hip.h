@@ -70,7 +70,7 @@ long long mmu_gemm_workspace_bytes(void);
  * kmask [B][S] int32 (1 = key may be attended; NULL = all). */
 int mmu_attn_fwd(const void* q, const void* k, const void* v, int ld, void* o, int ldo, float* lse,
                  const int* kmask, int B, int S, int H, int head_dim, float scale, int causal, void* stream);
-/* head_dim 128 only; delta: fp32 workspace of 2 * B * H * S floats ([0]: rowsum(dO * O), [1]: lse * log2 e). */
+/* head_dim 128 (Llama, causal) or 64 (CLIP tower, adapted by LoRA: non-causal); delta: fp32 workspace of 2 * B * H * S floats ([0]: rowsum(dO * O), [1]: lse * log2 e). */
 int mmu_attn_bwd(const void* q, const void* k, const void* v, int ld, const void* o, int ldo, const float* lse,
                  const int* kmask, const void* dout, int lddo, float* delta, void* dq, void* dk, void* dv,
                  int ldg, int B, int S, int H, int head_dim, float scale, int causal, void* stream);

@@ -191,6 +191,20 @@ __device__ __forceinline__ void store_grad_row(bf16* dst, const f32x16 (&acc)[4]
 }
 
 
+// Plain store of a gradient row fragment for any head_dim (acc[dt][4g+j] <-> d = dt*32 + 8g + 4*hl + j).
+template <int NDT>
+__device__ __forceinline__ void store_grad_row_plain(bf16* dst, const f32x16 (&acc)[NDT], int hl) {
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            bf16x4 t;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t[j] = f2bf(acc[dt][4 * g + j]);
+            *reinterpret_cast<bf16x4*>(dst + dt * 32 + 8 * g + 4 * hl) = t;
+        }
+}
+
 struct AttnArgs {
     const bf16* q;
     const bf16* k;
@@ -624,14 +638,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[dt][r] *= a.scale;
         bf16* op = a.dq + (rowbase + qrow) * a.ldg + hh * D;
-        const bf16* cr = nullptr;
-        const bf16* sr = nullptr;
-        if (a.rope_pos) {
-            const int pos = a.rope_pos[rowbase + qrow];
-            cr = a.rope_cos + (size_t)pos * 64;
-            sr = a.rope_sin + (size_t)pos * 64;
+        if constexpr (D == 128) {
+            const bf16* cr = nullptr;
+            const bf16* sr = nullptr;
+            if (a.rope_pos) {
+                const int pos = a.rope_pos[rowbase + qrow];
+                cr = a.rope_cos + (size_t)pos * 64;
+                sr = a.rope_sin + (size_t)pos * 64;
+            }
+            store_grad_row(op, acc, hl, cr, sr);
+        } else {
+            store_grad_row_plain<NDT>(op, acc, hl);  // head_dim 64 (CLIP tower): no rotary embedding
         }
-        store_grad_row(op, acc, hl, cr, sr);
     }
 }
 
@@ -648,7 +666,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
 // ------------------------------------------------------------------------------------------------
 template <int D, bool CAUSAL>
 __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
-    static_assert(D == 128, "backward is built for head_dim 128");
+    static_assert(D == 128 || D == 64, "backward is built for head_dim 128 (Llama) and 64 (CLIP tower)");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KVB = 128 * D * 2;  // K (or V) tile bytes
     constexpr int TB = 64 * D * 2;    // Q (or dO) pair-tile bytes (2 x 32 rows)
@@ -839,16 +857,17 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
         }
     }
     // sum the two query-half partials of every key group through LDS: waves 4-7 publish, waves 0-3 add + store.
-    // slab layout [kw][reg 0..127][lane] fp32 -> lane-contiguous, conflict-free; 4 x 32 KiB over the dead tiles.
+    // slab layout [kw][reg 0..2*NR-1][lane] fp32 -> lane-contiguous, conflict-free; 4 x (D/4) KiB over the dead tiles.
+    constexpr int NR = NDT * 16;  // accumulator registers of dK^T (and of dV^T)
     __syncthreads();
-    float* slab = reinterpret_cast<float*>(smem) + kw * (128 * 64);
+    float* slab = reinterpret_cast<float*>(smem) + kw * (2 * NR * 64);
     if (qh == 1) {
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 slab[(dt * 16 + r) * 64 + lane] = dk[dt][r];
-                slab[(64 + dt * 16 + r) * 64 + lane] = dv[dt][r];
+                slab[(NR + dt * 16 + r) * 64 + lane] = dv[dt][r];
             }
     }
     __syncthreads();
@@ -860,17 +879,22 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 dk[dt][r] = (dk[dt][r] + slab[(dt * 16 + r) * 64 + lane]) * a.scale;
-                dv[dt][r] += slab[(64 + dt * 16 + r) * 64 + lane];
+                dv[dt][r] += slab[(NR + dt * 16 + r) * 64 + lane];
             }
-        const bf16* cr = nullptr;
-        const bf16* sr = nullptr;
-        if (a.rope_pos) {
-            const int pos = a.rope_pos[rowbase + key];
-            cr = a.rope_cos + (size_t)pos * 64;
-            sr = a.rope_sin + (size_t)pos * 64;
+        if constexpr (D == 128) {
+            const bf16* cr = nullptr;
+            const bf16* sr = nullptr;
+            if (a.rope_pos) {
+                const int pos = a.rope_pos[rowbase + key];
+                cr = a.rope_cos + (size_t)pos * 64;
+                sr = a.rope_sin + (size_t)pos * 64;
+            }
+            store_grad_row(dkp, dk, hl, cr, sr);
+            store_grad_row(dvp, dv, hl, nullptr, nullptr);
+        } else {
+            store_grad_row_plain<NDT>(dkp, dk, hl);
+            store_grad_row_plain<NDT>(dvp, dv, hl);
         }
-        store_grad_row(dkp, dk, hl, cr, sr);
-        store_grad_row(dvp, dv, hl, nullptr, nullptr);
     }
 }
 
@@ -943,7 +967,7 @@ extern "C" int mmu_attn_fwd(const void* q, const void* k, const void* v, int ld,
     return causal ? launch_fwd<64, true>(a, s) : launch_fwd<64, false>(a, s);
 }
 
-// Backward (head_dim 128 only): needs q,k,v,o,lse of the forward plus dout; writes dq,dk,dv (row stride ldg,
+// Backward (head_dim 128 or 64): needs q,k,v,o,lse of the forward plus dout; writes dq,dk,dv (row stride ldg,
 // head h at column h*head_dim of each pointer) and uses delta [B][H][S] fp32 as workspace.
 extern "C" int mmu_attn_bwd_rope(const void* q, const void* k, const void* v, int ld, const void* o, int ldo,
                                  const float* lse, const int* kmask, const void* dout, int lddo, float* delta,
@@ -974,8 +998,10 @@ extern "C" int mmu_attn_bwd_rope(const void* q, const void* k, const void* v, in
     a.B = B; a.S = S; a.H = H; a.scale = scale;
     a.dout = (const bf16*)dout; a.lddo = lddo; a.delta = delta;
     a.dq = (bf16*)dq; a.dk = (bf16*)dk; a.dv = (bf16*)dv; a.ldg = ldg;
-    if (!attn_args_ok(a, head_dim) || head_dim != 128 || (lddo & 7) || (ldg & 3) || !lse || !delta) return -1;
+    if (!attn_args_ok(a, head_dim) || (lddo & 7) || (ldg & 3) || !lse || !delta) return -1;
+    if (head_dim != 128 && rope_pos) return -1;  // the fused inverse RoPE is a head_dim-128 (Llama) epilogue
     if (((uintptr_t)dout & 15) || (((uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 7)) return -1;
     hipStream_t s = (hipStream_t)stream;
+    if (head_dim == 64) return causal ? launch_bwd<64, true>(a, s) : launch_bwd<64, false>(a, s);
     return causal ? launch_bwd<128, true>(a, s) : launch_bwd<128, false>(a, s);
 }

@@ -683,7 +683,7 @@ class LlavaHIP(nn.Module):
     def _vision_backward(self, clip_saved, dfeats, n):
         """Reverse sweep through the adapted CLIP layers: only the LoRA adapters of the tower receive gradients (its
         base weights, LayerNorms and embeddings are frozen), so the chain carries dX only and stops at layer 0.
-        Attention (16 heads x 64) runs through the head_dim-128 backward kernels on zero-padded copies."""
+        Attention (16 heads x 64, non-causal) runs on the head_dim-64 instantiation of the backward kernels."""
         v, w = self.cfg.vision, self.w
         dev = self.device
         T, dv, H, D = v.num_patches + 1, v.hidden_size, v.num_heads, v.head_dim
@@ -691,7 +691,6 @@ class LlavaHIP(nn.Module):
         dh = torch.zeros(M, dv, device=dev, dtype=BF)
         dh.view(n, T, dv)[:, 1:].copy_(dfeats.view(n, T - 1, dv))  # the CLS row feeds nothing downstream
         scale = D ** -0.5
-        pad = lambda src: hip.head_pad(src, D, torch.empty(M, H * 128, device=dev, dtype=BF), 128, H)
         delta = torch.empty(2, n, H, T, device=dev, dtype=torch.float32)
         for i in reversed(range(len(clip_saved))):
             p = f"vision.layers.{i}."
@@ -707,14 +706,9 @@ class LlavaHIP(nn.Module):
             hip.layernorm_bwd(dy2, h2, w[p + "ln2.weight"], dh, dh2, v.layer_norm_eps)
             da = torch.empty_like(h)
             self._lin_bwd(p + "out.weight", dh2, a, da)
-            qp, kp, vp = pad(qkv[:, :dv]), pad(qkv[:, dv:2 * dv]), pad(qkv[:, 2 * dv:])
-            op, dop = pad(a), pad(da)
-            dqp = torch.empty(M, 3 * H * 128, device=dev, dtype=BF)
-            hip.attn_bwd(qp, kp, vp, op, lse, None, dop, delta, dqp[:, :H * 128], dqp[:, H * 128:2 * H * 128],
-                         dqp[:, 2 * H * 128:], n, T, H, 128, scale, False)
             dqkv = torch.empty(M, 3 * dv, device=dev, dtype=BF)
-            for j in range(3):
-                hip.head_pad(dqp[:, j * H * 128:(j + 1) * H * 128], 128, dqkv[:, j * dv:(j + 1) * dv], D, H)
+            hip.attn_bwd(qkv[:, :dv], qkv[:, dv:2 * dv], qkv[:, 2 * dv:], a, lse, None, da, delta, dqkv[:, :dv],
+                         dqkv[:, dv:2 * dv], dqkv[:, 2 * dv:], n, T, H, D, scale, False)  # native head_dim-64 kernels
             dy1 = torch.empty_like(h)
             self._lin_bwd(p + "qkv.weight", dqkv, y1, dy1)
             dhn = torch.empty_like(h)

@@ -186,10 +186,10 @@ def test_attn_fwd_left_pad_mask(dev):
     assert _relerr(got[valid], ref[valid]) < 1e-2
 
 
-@pytest.mark.parametrize("B,H,S,causal,pad", [(1, 1, 64, True, 0), (2, 2, 200, True, 0), (1, 2, 1088, True, 0),
-                                              (2, 2, 333, False, 0), (2, 2, 150, True, 20)])
-def test_attn_bwd(dev, B, H, S, causal, pad):
-    D = 128
+@pytest.mark.parametrize("B,H,S,causal,pad,D", [(1, 1, 64, True, 0, 128), (2, 2, 200, True, 0, 128), (1, 2, 1088, True, 0, 128),
+                                                (2, 2, 333, False, 0, 128), (2, 2, 150, True, 20, 128),
+                                                (2, 3, 577, False, 0, 64), (1, 2, 130, True, 0, 64), (2, 2, 70, False, 9, 64)])
+def test_attn_bwd(dev, B, H, S, causal, pad, D):
     g = torch.Generator().manual_seed(S)
     q, k, v, do = (torch.randn(B, H, S, D, generator=g).to(dev).to(BF) for _ in range(4))
     kmask = None
