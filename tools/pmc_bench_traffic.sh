@@ -7,7 +7,7 @@ OUT=$R/gpurun_out/pmc_bench
 mkdir -p $OUT
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 500 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/$c -- python3 $R/bench.py --steps 1 --warmup 0 --grad-accum 1 --no-cpu-baseline > $OUT/$c.log 2>&1 || echo "pass $c failed"
+  timeout -k 10 500 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/$c -- python3 $R/bench.py --steps 1 --warmup 0 --grad-accum 1 --no-cpu-baseline --no-reference-batch > $OUT/$c.log 2>&1 || echo "pass $c failed"
 done
 python3 - <<'PY'
 import csv, glob, json, os
@@ -25,7 +25,7 @@ for c in ("FETCH_SIZE","WRITE_SIZE"):
 n=res["FETCH_SIZE"]["launches"]
 import hashlib
 out={"gemm_src_sha16": hashlib.sha256(open(f"{R}/multimodal_unlearning_amd/csrc/gemm.hip","rb").read()).hexdigest()[:16],
-     "command":"rocprofv3 --kernel-trace --pmc <C> -- python3 bench.py --steps 1 --warmup 0 --grad-accum 1 --no-cpu-baseline",
+     "command":"rocprofv3 --kernel-trace --pmc <C> -- python3 bench.py --steps 1 --warmup 0 --grad-accum 1 --no-cpu-baseline --no-reference-batch",
      "gemm_launches":n,
      "fetch_bytes_per_launch": 2*res["FETCH_SIZE"]["sum_kb"]*1024/max(n,1),
      "write_bytes_per_launch": res["WRITE_SIZE"]["sum_kb"]*1024/max(res["WRITE_SIZE"]["launches"],1),
