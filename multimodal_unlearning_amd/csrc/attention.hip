@@ -22,6 +22,18 @@
 
 namespace {
 
+#ifdef MMU_ATTN_STAMP  // diagnostic build only (tools/attn_stamps.py): where a dK/dV workgroup spends its cycles
+__device__ unsigned long long g_attn_stamps[4 * 16384];
+__device__ __forceinline__ unsigned long long stamp_now() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+#define STAMP(var) const unsigned long long var = stamp_now()
+#else
+#define STAMP(var)
+#endif
+
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 
@@ -741,6 +753,11 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
         }
     };
 
+    STAMP(t_start);
+#ifdef MMU_ATTN_STAMP
+    unsigned long long t_wait = 0;
+    int n_iter = 0;
+#endif
     // block-resident K and V tiles (rows past S read the zero page)
     stage_rows<D, KIND_ROW, 128, 8>(smem, kp, a.ld, kvb * 128, S, wave, lane);
     stage_rows<D, KIND_ROW, 128, 8>(smem + KVB, vp, a.ld, kvb * 128, S, wave, lane);
@@ -750,8 +767,20 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
 
     for (int pr = pr0; pr < pr1; ++pr) {
         const int cur = (pr - pr0) & 1;
+        STAMP(t_w0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+#ifdef MMU_ATTN_STAMP
+        if (pr == pr0) t_wait = 0;  // the first wait belongs to the prologue (reported separately)
+        const unsigned long long t_w1 = stamp_now();
+        if (pr > pr0) t_wait += t_w1 - t_w0;
+        ++n_iter;
+#endif
+        if (pr == pr0) {
+#ifdef MMU_ATTN_STAMP
+            if (threadIdx.x == 0 && blockIdx.x < 16384) g_attn_stamps[4 * blockIdx.x + 0] = t_w1 - t_start;  // prologue
+#endif
+        }
         if (pr + 1 < pr1) stage(pr + 1, cur ^ 1);
         if (pr > pr0) {  // offsets follow the Q/dO buffer
 #pragma unroll
@@ -856,6 +885,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
             }
         }
     }
+    STAMP(t_loop_end);
     // sum the two query-half partials of every key group through LDS: waves 4-7 publish, waves 0-3 add + store.
     // slab layout [kw][reg 0..2*NR-1][lane] fp32 -> lane-contiguous, conflict-free; 4 x (D/4) KiB over the dead tiles.
     constexpr int NR = NDT * 16;  // accumulator registers of dK^T (and of dV^T)
@@ -896,6 +926,16 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
             store_grad_row_plain<NDT>(dvp, dv, hl);
         }
     }
+#ifdef MMU_ATTN_STAMP
+    {
+        const unsigned long long t_end = stamp_now();
+        if (threadIdx.x == 0 && blockIdx.x < 16384) {
+            g_attn_stamps[4 * blockIdx.x + 1] = t_loop_end - t_start;                      // start -> end of the sweep
+            g_attn_stamps[4 * blockIdx.x + 2] = t_wait;                                    // loop-top vmcnt + barrier waits
+            g_attn_stamps[4 * blockIdx.x + 3] = ((t_end - t_start) << 8) | (unsigned)n_iter;  // total cycles, iterations
+        }
+    }
+#endif
 }
 
 template <typename K>
@@ -1005,3 +1045,10 @@ extern "C" int mmu_attn_bwd_rope(const void* q, const void* k, const void* v, in
     if (head_dim == 64) return causal ? launch_bwd<64, true>(a, s) : launch_bwd<64, false>(a, s);
     return causal ? launch_bwd<128, true>(a, s) : launch_bwd<128, false>(a, s);
 }
+
+#ifdef MMU_ATTN_STAMP
+extern "C" int mmu_debug_read_attn_stamps(unsigned long long* host_out, int n_blocks) {
+    if (n_blocks < 1 || n_blocks > 16384) return -1;
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_attn_stamps), (size_t)n_blocks * 32, 0, hipMemcpyDeviceToHost);
+}
+#endif
