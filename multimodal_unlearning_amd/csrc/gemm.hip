@@ -24,11 +24,10 @@
 #include "common.h"
 
 struct RopeReq { const int* pos; const bf16* cos; const bf16* sin; int cols; };
-static RopeReq g_rope = {nullptr, nullptr, nullptr, 0};  // set only for the duration of mmu_gemm_bf16_rope
 static int g_force_tile = 0;  // mmu_gemm_set_tile
 static int g_group_m = 0;     // mmu_gemm_set_group_m
 static int g_persist = 1;     // mmu_gemm_set_persistent: 0 one workgroup per tile; 1 persistent (256 workgroups walk the tiles; default)
-static int g_num_cu = 256;    // MI355X
+static int g_num_cu = 256;    // MI355X; replaced by the device's own count on the first launch (cu_count())
 static int g_tail_split = 1;     // mmu_gemm_set_tail_split: 0 off, 1 heuristic, 2 whenever the remainder is <= half a round
 static float* g_sk_ws = nullptr;  // mmu_gemm_set_workspace
 static size_t g_sk_ws_bytes = 0;
@@ -743,9 +742,26 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
 #undef G256_MMA
 }
 
+// Compute units of the current device, read once (the tail split and the persistent grid are sized by it; the
+// split-K workspace contract stays 256 slots = mmu_gemm_workspace_bytes()).
+static int cu_count() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0 && v <= 256)
+            n = v;
+        else
+            n = 256;
+        g_num_cu = n;
+    }
+    return n;
+}
+
 template <bool AT, bool BT, int EPI>
 int launch_epi(GemmArgs a, hipStream_t stream) {
     static bool configured = false;
+    cu_count();
     auto kern = gemm256_kernel<AT, BT, EPI>;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -769,7 +785,7 @@ int launch_epi(GemmArgs a, hipStream_t stream) {
     if (split > 8) split = 8;
     if (split > nk) split = nk;
     bool sk = g_tail_split && split >= 2 && !a.rope_pos && !(g_tail_split == 3 && EPI == 1) && g_sk_ws &&
-              g_sk_ws_bytes >= (size_t)g_num_cu * 65536 * sizeof(float);
+              g_sk_ws_bytes >= (size_t)256 * 65536 * sizeof(float);
     if (sk && g_tail_split != 2) {
         const double saving_us = (1.0 - 1.0 / split) * nk * 1.45;  // measured us per K-tile of one tile
         const double cost_us = 15.0 + 0.1 * rem * split;           // partial write + fold read at ~5 TB/s
@@ -837,9 +853,18 @@ extern "C" int mmu_gemm_bf16(int layout, const void* A, const void* B, void* C, 
 
 // Same as mmu_gemm_bf16 plus a fused low-rank update acc += U[M][lora_k] * BL[N][lora_k]^T (both row-major,
 // contiguous, 16-B aligned; lora_k in {32, 64}; pad unused columns with zeros).  LoRA: U = s * x A^T, BL = B.
+static int gemm_dispatch(int layout, const void* A, const void* B, void* C, const void* bias, const void* resid, int M,
+                         int N, int K, int lda, int ldb, int ldc, int ldr, int act, int accumulate, const void* lora_u,
+                         const void* lora_b, int lora_k, const RopeReq& rope, void* stream);
 extern "C" int mmu_gemm_bf16_lora(int layout, const void* A, const void* B, void* C, const void* bias,
                                   const void* resid, int M, int N, int K, int lda, int ldb, int ldc, int ldr, int act,
                                   int accumulate, const void* lora_u, const void* lora_b, int lora_k, void* stream) {
+    return gemm_dispatch(layout, A, B, C, bias, resid, M, N, K, lda, ldb, ldc, ldr, act, accumulate, lora_u, lora_b, lora_k,
+                         RopeReq{nullptr, nullptr, nullptr, 0}, stream);
+}
+static int gemm_dispatch(int layout, const void* A, const void* B, void* C, const void* bias, const void* resid, int M,
+                         int N, int K, int lda, int ldb, int ldc, int ldr, int act, int accumulate, const void* lora_u,
+                         const void* lora_b, int lora_k, const RopeReq& rope, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0) return -1;
     if (lora_k != 0 && (lora_k != 32 && lora_k != 64)) return -1;
     if (lora_k != 0 && (!lora_u || !lora_b || (((uintptr_t)lora_u | (uintptr_t)lora_b) & 15))) return -1;
@@ -855,7 +880,7 @@ extern "C" int mmu_gemm_bf16_lora(int layout, const void* A, const void* B, void
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldr = ldr;
     a.act = act; a.accumulate = accumulate;
     a.lora_u = (const bf16*)lora_u; a.lora_b = (const bf16*)lora_b; a.lora_k = lora_k;
-    a.rope_pos = g_rope.pos; a.rope_cos = g_rope.cos; a.rope_sin = g_rope.sin; a.rope_cols = g_rope.cols;
+    a.rope_pos = rope.pos; a.rope_cos = rope.cos; a.rope_sin = rope.sin; a.rope_cols = rope.cols;
     // the 256^2 kernel's epilogue moves 16-B chunks of C / residual / bias
     const bool use256 = pick_256(M, N, K) && !(ldc & 7) && !(resid && ((ldr & 7) || ((uintptr_t)resid & 15))) &&
                         !(bias && ((uintptr_t)bias & 15));
@@ -903,11 +928,10 @@ extern "C" int mmu_gemm_bf16_rope(int layout, const void* A, const void* B, void
                                   const int* rope_pos, const void* rope_cos, const void* rope_sin, int rope_cols,
                                   void* stream) {
     if (!rope_pos || !rope_cos || !rope_sin || (rope_cols & 127) || rope_cols > N) return -1;
-    g_rope = {rope_pos, (const bf16*)rope_cos, (const bf16*)rope_sin, rope_cols};
-    const int rc = mmu_gemm_bf16_lora(layout, A, B, C, nullptr, nullptr, M, N, K, lda, ldb, ldc, 0, 0, 0, lora_u, lora_b,
-                                      lora_k, stream);
-    g_rope = {nullptr, nullptr, nullptr, 0};
-    return rc;
+    // the request travels in the kernel arguments (no process-global state: safe from any host thread / stream)
+    const RopeReq rope = {rope_pos, (const bf16*)rope_cos, (const bf16*)rope_sin, rope_cols};
+    return gemm_dispatch(layout, A, B, C, nullptr, nullptr, M, N, K, lda, ldb, ldc, 0, 0, 0, lora_u, lora_b, lora_k, rope,
+                         stream);
 }
 
 // Split-K GEMM for SMALL outputs (skinny LoRA wgrads): grid.y = splits blocks per tile each reduce a K range and
@@ -928,18 +952,22 @@ extern "C" int mmu_gemm_bf16_splitk(int layout, const void* A, const void* B, fl
     a.kt_per_split = (nk + splits - 1) / splits;
     const int ny = (nk + a.kt_per_split - 1) / a.kt_per_split;
     hipStream_t s = (hipStream_t)stream;
-    auto go = [&](auto kern) -> int {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           4 * TILE_BYTES);
-        if (e != hipSuccess) return (int)e;
+    auto go = [&](auto kern, bool& configured) -> int {
+        if (!configured) {  // once per kernel instantiation, not per launch
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
+            if (e != hipSuccess) return (int)e;
+            configured = true;
+        }
         hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n, ny), dim3(256), 4 * TILE_BYTES, s, a);
         hipError_t e2 = hipGetLastError();
         return (int)e2;
     };
+    static bool cfg[3] = {false, false, false};
     switch (layout) {
-        case 0: return go(gemm_bf16_kernel<false, false, 3>);
-        case 1: return go(gemm_bf16_kernel<false, true, 3>);
-        case 2: return go(gemm_bf16_kernel<true, true, 3>);
+        case 0: return go(gemm_bf16_kernel<false, false, 3>, cfg[0]);
+        case 1: return go(gemm_bf16_kernel<false, true, 3>, cfg[1]);
+        case 2: return go(gemm_bf16_kernel<true, true, 3>, cfg[2]);
         default: return -1;
     }
 }
@@ -974,7 +1002,7 @@ extern "C" int mmu_gemm_set_workspace(void* ws, long long bytes) {
     g_sk_ws_bytes = ws ? (size_t)bytes : 0;
     return 0;
 }
-extern "C" long long mmu_gemm_workspace_bytes(void) { return (long long)g_num_cu * 65536 * sizeof(float); }
+extern "C" long long mmu_gemm_workspace_bytes(void) { return 256LL * 65536 * sizeof(float); }
 
 #ifdef MMU_CLOCK_STAMP
 // Diagnostic build only: copy the per-workgroup {shader cycles, 100 MHz ticks} of the LAST 256^2 launch to the host.

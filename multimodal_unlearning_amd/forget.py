@@ -44,8 +44,10 @@ class ForgetRunConfig(ForgetConfig):
     save_model: bool = True
     optimizer: str = "adamw"                    # "adamw" (fp32 moments) | "adamw8bit" (the reference's adamw_bnb_8bit)
     dp_mode: str = "allreduce"                  # "allreduce" | "rs_ag"
-    seq_len: int = 0                            # synthetic data: 0 = 576 image + 512 text tokens
+    seq_len: int = 0                            # synthetic data: 0 = 576 image + 512 text tokens (text: 500)
     max_steps: int = 0                          # 0 = the reference's formula
+    modality: str = "mm"                        # "mm": mm/forget.py (image + QA pairs, MMTrainerForgetting);
+                                                # "text": nlp/forget.py (TOFU-style QA, CustomTrainerForgetting, tuple inputs)
 
 
 def parse_overrides(argv: List[str], cfg: ForgetRunConfig) -> ForgetRunConfig:
@@ -108,6 +110,56 @@ class _SyntheticPairs:
                                  splits=self.splits, device=device)
 
 
+class _SyntheticText:
+    """`synthetic:<n>` for modality=text: [B, 500] right-padded tuples (nlp/data_module.py:10-43 layout)."""
+
+    def __init__(self, n, cfg, n_splits, seq_len, seed):
+        self.n, self.cfg, self.n_splits, self.seq_len, self.seed = n, cfg, n_splits, seq_len or 500, seed
+
+    def __len__(self):
+        return self.n
+
+    def batch(self, indices, device):
+        from .synthetic import make_text_split
+
+        S, B = self.seq_len, len(indices)
+        out = []
+        for j in range(self.n_splits):
+            sp = make_text_split(self.cfg, B, S, seed=self.seed * 100003 + int(indices[0]) * 7 + j, n_question=S // 4,
+                                 right_pad=[(7 * (int(i) + j)) % max(1, S // 5) for i in indices], device=device)
+            out.append((sp["input_ids"], sp["labels"], sp["attention_mask"]))
+        return out
+
+
+class _JsonlText:
+    """Local JSON-lines {"question", "answer"} rows through TextForgetPairs + custom_data_collator_forget."""
+
+    def __init__(self, rc, tokenizer_path):
+        from transformers import AutoTokenizer
+
+        from .collator import TokenizerAdapter
+        from .text_collator import TextForgetPairs
+
+        read = lambda p: [json.loads(line) for line in open(p) if line.strip()]
+        tok = AutoTokenizer.from_pretrained(tokenizer_path, local_files_only=True)
+        idk = []
+        idk_path = os.path.join(os.path.dirname(rc.forget_data_path), "idontknow.jsonl")
+        if os.path.exists(idk_path):
+            idk = [line.strip() for line in open(idk_path) if line.strip()]
+        self.pairs = TextForgetPairs(read(rc.forget_data_path), read(rc.retain_data_path), TokenizerAdapter.from_hf(tok),
+                                     tok.eos_token_id, max_length=rc.seq_len or 500, loss_type=rc.forget_loss,
+                                     idk_answers=idk)
+
+    def __len__(self):
+        return len(self.pairs)
+
+    def batch(self, indices, device):
+        from .text_collator import custom_data_collator_forget
+
+        col = custom_data_collator_forget([self.pairs[int(i)] for i in indices])
+        return [tuple(t.to(device) for t in split) for split in col]
+
+
 class _JsonlPairs:
     """Local JSON-lines forget / retain files through MixedForgetPairs + the reference-exact collator."""
 
@@ -156,7 +208,7 @@ def run(rc: ForgetRunConfig):
     from .checkpoint import load_pretrained, save_pretrained
     from .engine import ForgetEngine, init_distributed, shard_indices, steps_from_reference_formula
     from .llava import LlavaHIP, LoraSpec
-    from .trainer import MMTrainerForgetting
+    from .trainer import CustomTrainerForgetting, MMTrainerForgetting
 
     rank, local, world = init_distributed()
     if not torch.cuda.is_available():
@@ -181,7 +233,18 @@ def run(rc: ForgetRunConfig):
     lt = rc.forget_loss
     splits = {"DPO": ("forget", "retain", "idk"), "LLMU": ("forget", "retain", "idk"), "IDK": ("idk", "retain"),
               "SKU": ("forget", "retain", "random")}.get(lt.upper(), ("forget", "retain"))
-    if rc.forget_data_path.startswith("synthetic:"):
+    text = rc.modality == "text"
+    if rc.modality not in ("mm", "text"):
+        raise SystemExit(f"modality {rc.modality!r}: expected 'mm' or 'text'")
+    if text:
+        n_splits = 3 if lt in ("dpo", "LLMU") else 2  # nlp/forget.py: TextForgetDatasetDPOQA adds the idk split
+        if rc.forget_data_path.startswith("synthetic:"):
+            data = _SyntheticText(int(rc.forget_data_path.split(":")[1]), cfg, n_splits, rc.seq_len, rc.seed)
+        else:
+            if not rc.tokenizer_path:
+                raise SystemExit("JSON-lines data need tokenizer_path=<local tokenizer directory>")
+            data = _JsonlText(rc, rc.tokenizer_path)
+    elif rc.forget_data_path.startswith("synthetic:"):
         if "random" in splits:
             raise SystemExit("the synthetic generator has no nested 'random' split: use JSON-lines data for sku")
         data = _SyntheticPairs(int(rc.forget_data_path.split(":")[1]), cfg, splits, rc.seq_len, rc.seed)
@@ -207,9 +270,13 @@ def run(rc: ForgetRunConfig):
     teacher = None
     if need_teacher:  # the reference loads the same checkpoint a second time (mm/forget.py:91-99)
         teacher = LlavaHIP(cfg, params, device=dev, trainable=False, seed=rc.seed, init="device" if params is None else "numpy")
-    trainer = MMTrainerForgetting(model=model, teacher_model=teacher, forget_loss=lt, loss_beta=rc.loss_beta,
-                                  l1_lambda=rc.l1_lambda, l0_lambda=rc.l0_lambda, l_norm_from=rc.l_norm_from,
-                                  loss_args={"bad_weight": 2.5, "random_weight": 1.0, "normal_weight": 0.5})  # :186
+    if text:  # nlp/forget.py:180-197 (oracle_model=, case-sensitive loss names, L1/L0 against the oracle)
+        trainer = CustomTrainerForgetting(model=model, oracle_model=teacher, forget_loss=lt, loss_beta=rc.loss_beta,
+                                          l1_lambda=rc.l1_lambda, l0_lambda=rc.l0_lambda)
+    else:
+        trainer = MMTrainerForgetting(model=model, teacher_model=teacher, forget_loss=lt, loss_beta=rc.loss_beta,
+                                      l1_lambda=rc.l1_lambda, l0_lambda=rc.l0_lambda, l_norm_from=rc.l_norm_from,
+                                      loss_args={"bad_weight": 2.5, "random_weight": 1.0, "normal_weight": 0.5})  # :186
     engine = ForgetEngine(model, trainer, rc, total_steps=max_steps, warmup_steps=warmup, optimizer=rc.optimizer,
                           dp_mode=rc.dp_mode)
 

@@ -743,3 +743,17 @@ def test_forget_entry_point_end_to_end(dev, tmp_path):
     back = load_pretrained(tiny_test_config(), out)
     assert torch.equal(back["lm_head.weight"].to(torch.bfloat16), eng.model.w["lm_head.weight"].cpu())
     assert eng.trainer.teacher_model is not None  # KL: the frozen copy of the starting weights
+
+
+def test_forget_entry_point_text_modality(dev, tmp_path):
+    """BASELINE config 1 through the entry point: modality=text (nlp/forget.py's surface: CustomTrainerForgetting, tuple
+    inputs, LoRA r=8, grad_ascent) on the tiny architecture; the run saves base weights + a peft-layout adapter."""
+    from multimodal_unlearning_amd.forget import ForgetRunConfig, parse_overrides, run
+
+    out = str(tmp_path / "text_run")
+    rc = parse_overrides(["model_family=tiny", "modality=text", f"save_dir={out}", "forget_data_path=synthetic:8",
+                          "batch_size=2", "gradient_accumulation_steps=1", "num_epochs=2", "seq_len=48", "lr=1e-3",
+                          "forget_loss=grad_ascent", "LoRA.r=8"], ForgetRunConfig())
+    eng = run(rc)
+    assert eng.opt_step == 2 * 8 // 2 and type(eng.trainer).__name__ == "CustomTrainerForgetting"
+    assert os.path.exists(os.path.join(out, "adapter_model.safetensors")) and os.path.exists(os.path.join(out, "adapter_config.json"))
