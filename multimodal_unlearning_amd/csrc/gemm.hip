@@ -436,7 +436,7 @@ __global__ __launch_bounds__(256) void sk_fold_kernel(GemmArgs p, int epi) {
     const int kc = (nk + p.sk_split - 1) / p.sk_split;
     int m0, n0;
     decode_tile(p, p.sk_first + r, m0, n0);
-    for (int idx = blockIdx.y * 256 + threadIdx.x; idx < 16384; idx += gridDim.y * 256) {
+    auto partial_sum = [&](int idx) {
         f32x4 sum = {0.f, 0.f, 0.f, 0.f};
         for (int i = 0; i < p.sk_split; ++i) {
             if (i * kc >= nk) break;  // empty range: that worker wrote nothing
@@ -445,11 +445,38 @@ __global__ __launch_bounds__(256) void sk_fold_kernel(GemmArgs p, int epi) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) sum[j] += v[j];
         }
+        return sum;
+    };
+    for (int idx = blockIdx.y * 256 + threadIdx.x; idx < 16384; idx += gridDim.y * 256) {
         const int frag = idx >> 9, wave = (idx >> 6) & 7, lane = idx & 63;
         const int nt = frag & 1, b = (frag >> 1) & 1, mt = (frag >> 2) & 3, a = frag >> 4;
         const int wm = wave >> 2, wn = wave & 3;
         const int m = m0 + wm * 128 + a * 64 + mt * 16 + (lane & 15);
-        const int n = n0 + (wn >> 1) * 128 + b * 64 + (wn & 1) * 32 + nt * 16 + 4 * (lane >> 4);
+        const int cih = (wn & 1) * 32 + nt * 16 + 4 * (lane >> 4);  // column inside the 128-wide head (< 64)
+        const int n = n0 + (wn >> 1) * 128 + b * 64 + cih;
+        if (p.rope_pos && n - b * 64 < p.rope_cols) {
+            // fused-RoPE tile: the b = 0 thread of a (c, c + 64) pair folds both halves and rotates them with the
+            // arithmetic of the GEMM kernel's own epilogue (bf16-rounded x, cos / sin tables, rounded products)
+            if (b) continue;
+            const f32x4 s0 = partial_sum(idx), s1 = partial_sum(idx + 1024);  // frag | 2
+            f32x4 y0 = s0, y1 = s1;
+            if (m < p.M) {
+                const int pos = p.rope_pos[m];
+                const bf16x4 c4 = *reinterpret_cast<const bf16x4*>(p.rope_cos + (size_t)pos * 64 + cih);
+                const bf16x4 s4 = *reinterpret_cast<const bf16x4*>(p.rope_sin + (size_t)pos * 64 + cih);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float x1 = round_bf16(s0[j]), x2 = round_bf16(s1[j]);
+                    const float cf = bf2f(c4[j]), sf = bf2f(s4[j]);
+                    y0[j] = round_bf16(x1 * cf) + round_bf16(-x2 * sf);
+                    y1[j] = round_bf16(x2 * cf) + round_bf16(x1 * sf);
+                }
+            }
+            epi_store<0>(p, m, n, y0);
+            epi_store<0>(p, m, n + 64, y1);
+            continue;
+        }
+        const f32x4 sum = partial_sum(idx);
         // the GEMM kernel's own epilogue on the summed tile: 0 plain, 1 bias / activation / residual (HF rounding
         // points), 2 accumulate into C
         if (epi == 1) epi_store<1>(p, m, n, sum);
@@ -776,7 +803,7 @@ int launch_epi(GemmArgs a, hipStream_t stream) {
     // Split-K tail: with T tiles on 256 CUs the last T % 256 tiles occupy a whole round; when they are at most half a
     // round, cut each into S = 256 / rem K ranges over rem * S extra workgroups (gate_up wgrad: 96 tiles x 2 ranges
     // = 5.5 rounds instead of 6).  The fold kernel applies the tile's epilogue (plain, bias / activation / residual
-    // with the HF rounding points, or accumulate) to the summed partials; only the fused-RoPE epilogue is never split.
+    // with the HF rounding points, accumulate, or the fused RoPE rotation of the q|k columns) to the summed partials.
     // With the reference's default micro-batch (2 pairs = 4352 tokens = 17 tile rows) the o / down projections are
     // 272 tiles = 1.06 rounds: their 16 remainder tiles become 128 K-range workers instead of a second round.
     const int rem = tiles % g_num_cu;
@@ -784,7 +811,7 @@ int launch_epi(GemmArgs a, hipStream_t stream) {
     int split = rem ? g_num_cu / rem : 0;
     if (split > 8) split = 8;
     if (split > nk) split = nk;
-    bool sk = g_tail_split && split >= 2 && !a.rope_pos && !(g_tail_split == 3 && EPI == 1) && g_sk_ws &&
+    bool sk = g_tail_split && split >= 2 && !(g_tail_split == 3 && (EPI == 1 || a.rope_pos)) && g_sk_ws &&
               g_sk_ws_bytes >= (size_t)256 * 65536 * sizeof(float);
     if (sk && g_tail_split != 2) {
         const double saving_us = (1.0 - 1.0 / split) * nk * 1.45;  // measured us per K-tile of one tile

@@ -568,6 +568,28 @@ def test_fused_rope_epilogue_and_bwd_store(dev):
     out = torch.empty_like(ref)
     assert hip.gemm_rope(x, w, out, pos, cos_t, sin_t, 2 * dt)
     assert torch.equal(out, ref)
+    # the split-K tail of a fused-RoPE GEMM: the fold kernel rotates the remainder tiles (30 x 12 = 360 tiles = 256 in
+    # the kernel's epilogue + 104 through the fold; and 17 x 3 = 51 tiles, all through the fold); integer x / w: exact
+    hip.ensure_gemm_workspace(dev)
+    for (Mb, Hb) in ((7680, 8), (4352, 2)):
+        dtb, Sb = Hb * D, Mb // 2
+        xi = _rand_int((Mb, 512), dev, -2, 2, seed=31)
+        wi = _rand_int((3 * dtb, 512), dev, -2, 2, seed=32)
+        posb = torch.arange(Sb, dtype=torch.int32, device=dev).repeat(2)
+        cb = torch.empty(Sb, D // 2, device=dev, dtype=BF)
+        sb = torch.empty(Sb, D // 2, device=dev, dtype=BF)
+        hip.rope_table(cb, sb, Sb, D, 10000.0)
+        refb = torch.empty(Mb, 3 * dtb, device=dev, dtype=BF)
+        hip.gemm_set_tail_split(0)
+        hip.gemm(hip.NT, xi, wi, refb)
+        hip.rope(refb, posb, cb, sb, Hb, Hb, D, dtb)
+        try:
+            hip.gemm_set_tail_split(2)
+            outb = torch.empty_like(refb)
+            assert hip.gemm_rope(xi, wi, outb, posb, cb, sb, 2 * dtb)
+        finally:
+            hip.gemm_set_tail_split(1)
+        assert torch.equal(outb, refb), (Mb, Hb)
     # backward stores
     qkv = ref
     o = torch.empty(M, dt, device=dev, dtype=BF)
