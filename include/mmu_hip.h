@@ -81,6 +81,11 @@ int mmu_attn_bwd_rope(const void* q, const void* k, const void* v, int ld, const
                       int B, int S, int H, int head_dim, float scale, int causal, const int* rope_pos,
                       const void* rope_cos, const void* rope_sin, void* stream);
 
+/* dK/dV kernel of the head_dim-128 backward: low byte 8 = eight waves, K / V tiles in LDS; 4 = four waves (one per SIMD,
+ * 512 registers), persistent, K / V fragments in registers, 4-stage Q/dO ring running across item seams.  Bits 8 and up:
+ * workgroups of the four-wave kernel (0 = one per CU, else a multiple of 8).  Process-wide tuning / A-B switch. */
+int mmu_attn_set_dkdv_variant(int variant);
+
 /* ---- Norms (LlamaRMSNorm / CLIP LayerNorm; SURVEY §8a K2,K7) ---- */
 int mmu_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int M, int d, float eps, void* stream);
 int mmu_rmsnorm_bwd_nparts(int M); /* dw_part must hold nparts*d floats */

@@ -12,7 +12,10 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libmmu_hip.so")
-SOURCES = ["gemm.hip", "attention.hip", "elementwise.hip", "loss.hip", "optim.hip"]
+SOURCES = ["gemm.hip", "attention.hip", "attention_dkdv4.hip", "elementwise.hip", "loss.hip", "optim.hip"]
+# per-file extra flags (none at present; tools/build_variant.py honours the table too)
+EXTRA_FLAGS: dict[str, list[str]] = {}
+HEADERS = ["common.h", "attention_common.h"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-variable"]
 
@@ -25,15 +28,15 @@ def _stale(target: str, deps: list[str]) -> bool:
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
-    hdr = os.path.join(CSRC, "common.h")
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     objs = []
     jobs = []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
         obj = os.path.join(CSRC, s.replace(".hip", ".o"))
         objs.append(obj)
-        if force or _stale(obj, [src, hdr]):
-            jobs.append([HIPCC, *FLAGS, "-c", src, "-o", obj])
+        if force or _stale(obj, [src, *hdrs]):
+            jobs.append([HIPCC, *FLAGS, *EXTRA_FLAGS.get(s, []), "-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:

@@ -16,257 +16,14 @@
 // LDS tiles are [rows][D] row-major, lane-linear as LDS-DMA writes them, XOR-swizzled on the per-lane
 // source address and on the reads.  D=128 (256-B rows): chunk ^= ((row&3)<<2)|((row>>2)&3), which is
 // conflict-free for both ds_read_b128 row reads and transposed reads (guide T10 image (b)).
-#include <type_traits>
-
-#include "common.h"
+#include "attention_common.h"
 
 namespace {
-
-#ifdef MMU_ATTN_STAMP  // diagnostic build only (tools/attn_stamps.py): where a dK/dV workgroup spends its cycles
-__device__ unsigned long long g_attn_stamps[4 * 16384];
-__device__ __forceinline__ unsigned long long stamp_now() {
-    unsigned long long t;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-    return t;
-}
-#define STAMP(var) const unsigned long long var = stamp_now()
-#else
-#define STAMP(var)
-#endif
-
-constexpr float LOG2E = 1.4426950408889634f;
-constexpr float LN2 = 0.6931471805599453f;
-
-enum { KIND_ROW = 0, KIND_TR = 1 };
-
-template <int D, int KIND>
-__device__ __forceinline__ int swz(int r) {
-    if (D == 128) return ((r & 3) << 2) | ((r >> 2) & 3);
-    // D == 64: 128-B rows (two rows per 256-B bank row)
-    return KIND == KIND_ROW ? ((r >> 1) & 7) : (((r >> 1) & 1) << 2);
-}
-
-// Stage R rows x D bf16 of a row-major matrix (row stride ld elements) into a swizzled LDS tile.
-// Rows >= row_limit read the zero page.
-template <int D, int KIND, int R, int NW = 4>
-__device__ __forceinline__ void stage_rows(char* tile, const bf16* __restrict__ g, int ld, int row0, int row_limit,
-                                           int wave, int lane) {
-    constexpr int ROWB = D * 2, RPI = 1024 / ROWB, CPR = ROWB / 16, NI = R / RPI, PW = NI / NW;
-    static_assert(PW >= 1 && PW * NW == NI, "tile does not split evenly over the waves");
-    const bf16* zero = reinterpret_cast<const bf16*>(mmu_zero16);
-#pragma unroll
-    for (int i = 0; i < PW; ++i) {
-        const int t = wave * PW + i;
-        const int r = t * RPI + lane / CPR;
-        const int c = (lane % CPR) ^ swz<D, KIND>(r);
-        const bf16* src = (row0 + r < row_limit) ? (g + (size_t)(row0 + r) * ld + c * 8) : zero;
-        glds16(src, tile + t * 1024);
-    }
-}
-
-// The same staging with the per-lane part of the address (row * ld + swizzled chunk) computed ONCE: per tile only a
-// wave-uniform base pointer moves, and full tiles skip the per-lane bounds select (the per-block address arithmetic of
-// stage_rows was ~150 issue slots in front of every block's MFMAs).
-template <int D, int KIND, int R, int NW = 4>
-struct RowStager {
-    static constexpr int ROWB = D * 2, RPI = 1024 / ROWB, CPR = ROWB / 16, NI = R / RPI, PW = NI / NW;
-    int off[PW];  // elements from the tile's first row
-    int row[PW];
-    __device__ __forceinline__ void init(int ld, int wave, int lane) {
-#pragma unroll
-        for (int i = 0; i < PW; ++i) {
-            const int t = wave * PW + i;
-            const int r = t * RPI + lane / CPR;
-            const int c = (lane % CPR) ^ swz<D, KIND>(r);
-            row[i] = r;
-            off[i] = r * ld + c * 8;
-        }
-    }
-    __device__ __forceinline__ void issue(char* tile, const bf16* __restrict__ g, int ld, int row0, int row_limit,
-                                          int wave) const {
-        const bf16* base = g + (size_t)row0 * ld;
-        if (row0 + R <= row_limit) {
-#pragma unroll
-            for (int i = 0; i < PW; ++i) glds16(base + off[i], tile + (wave * PW + i) * 1024);
-        } else {
-            const bf16* zero = reinterpret_cast<const bf16*>(mmu_zero16);
-#pragma unroll
-            for (int i = 0; i < PW; ++i)
-                glds16((row0 + row[i] < row_limit) ? base + off[i] : zero, tile + (wave * PW + i) * 1024);
-        }
-    }
-};
-
-// Row-read fragment: lane l gets tile[base + (l&31)][16*ks + 8*(l>>5) + 0..7]
-template <int D, int KIND>
-__device__ __forceinline__ bf16x8 row_frag(const MMU_LDS char* tile, int base, int ks, int lane) {
-    const int r = base + (lane & 31);
-    const int ch = 2 * ks + (lane >> 5);
-    return *(const MMU_LDS bf16x8*)(tile + r * (D * 2) + ((ch ^ swz<D, KIND>(r)) << 4));
-}
-
-// Transposed fragment: lane l gets tile[rbase + 16*s + 8*(j>>2) + 4*(l>>5) + (j&3)][c0 + (l&31)], j = 0..7
-// (the k order of an accumulator tile used as the other operand, guide §3).
-template <int D, int KIND>
-__device__ __forceinline__ bf16x8 tr_frag(const MMU_LDS char* tile, int rbase, int s, int c0, int lane) {
-    const int g = lane >> 4, gb = g & 1, h = g >> 1, i = lane & 15, q = i >> 2, p = i & 3;
-    const int r1 = rbase + 16 * s + 4 * h + q;
-    const int r2 = r1 + 8;
-    const int ch = (c0 >> 3) + 2 * gb + (p >> 1);
-    const int sub = (p & 1) << 3;
-    const MMU_LDS char* a1 = tile + r1 * (D * 2) + ((ch ^ swz<D, KIND>(r1)) << 4) + sub;
-    const MMU_LDS char* a2 = tile + r2 * (D * 2) + ((ch ^ swz<D, KIND>(r2)) << 4) + sub;
-    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((MMU_LDS bf16x4*)a1);
-    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((MMU_LDS bf16x4*)a2);
-    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-}
-
-
-// Per-lane LDS byte offsets of the 32x32x16 fragments, relative to a tile address whose fragment starts at a row
-// that is a multiple of 32 (row / transposed reads then only add compile-time constants).
-template <int D, int KIND>
-struct FragOffsets {
-    int row[D / 16];               // row fragment of k-step ks: row (lane&31), 16-B chunk 2ks + (lane>>5)
-    int tr1[D / 32], tr2[D / 32];  // transposed fragment, 32-column block dt, k-step 0 (k-step 1: + 16 rows)
-    __device__ __forceinline__ void init(int lane) {
-        const int hl = lane >> 5, r = lane & 31;
-#pragma unroll
-        for (int ks = 0; ks < D / 16; ++ks) row[ks] = r * (D * 2) + (((2 * ks + hl) ^ swz<D, KIND>(r)) << 4);
-        const int g = lane >> 4, gb = g & 1, h = g >> 1, i = lane & 15, q = i >> 2, pp = i & 3;
-        const int r1 = 4 * h + q, r2 = r1 + 8, sub = (pp & 1) << 3;
-#pragma unroll
-        for (int dt = 0; dt < D / 32; ++dt) {
-            const int ch = 4 * dt + 2 * gb + (pp >> 1);
-            tr1[dt] = r1 * (D * 2) + ((ch ^ swz<D, KIND>(r1)) << 4) + sub;
-            tr2[dt] = r2 * (D * 2) + ((ch ^ swz<D, KIND>(r2)) << 4) + sub;
-        }
-    }
-    // Double-buffered tiles sit 2^k bytes apart: the offsets follow the buffer by an in-place XOR (D/16 + D/16 v_xor per
-    // block) instead of one v_add of the tile base in front of every LDS read (72 per block in the backward kernels:
-    // a quarter of their VALU instructions); everything else about an address is an instruction immediate.
-    __device__ __forceinline__ void toggle_rows(int bit) {
-#pragma unroll
-        for (int ks = 0; ks < D / 16; ++ks) row[ks] ^= bit;
-    }
-    __device__ __forceinline__ void toggle_tr(int bit) {
-#pragma unroll
-        for (int dt = 0; dt < D / 32; ++dt) { tr1[dt] ^= bit; tr2[dt] ^= bit; }
-    }
-};
-
-__device__ __forceinline__ bf16x8 tr_load(const MMU_LDS char* p1, const MMU_LDS char* p2) {
-    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((MMU_LDS bf16x4*)p1);
-    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((MMU_LDS bf16x4*)p2);
-    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-}
-
-__device__ __forceinline__ bf16x8 pack8(const f32x16& v, int s) {
-    bf16x8 r;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) r[j] = f2bf(v[8 * s + j]);
-    return r;
-}
-
-__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
-
-// Store one gradient row fragment held as acc[dt][4g+j] <-> d = dt*32 + 8g + 4*hl + j (D = 128), optionally applying
-// the transpose rotation of RoPE to the (d, d+64) pairs = (dt, dt+2): same arithmetic as rope_kernel(inverse=1) on the
-// bf16-rounded gradient.
-__device__ __forceinline__ void store_grad_row(bf16* dst, const f32x16 (&acc)[4], int hl, const bf16* cos_row,
-                                               const bf16* sin_row) {
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int d = dt * 32 + 8 * g + 4 * hl;  // < 64
-            bf16x4 t, u;
-            if (cos_row) {
-                const bf16x4 c4 = *reinterpret_cast<const bf16x4*>(cos_row + d);
-                const bf16x4 s4 = *reinterpret_cast<const bf16x4*>(sin_row + d);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float a = round_bf16(acc[dt][4 * g + j]), b = round_bf16(acc[dt + 2][4 * g + j]);
-                    const float cf = bf2f(c4[j]), sf = bf2f(s4[j]);
-                    t[j] = f2bf(round_bf16(a * cf) + round_bf16(b * sf));
-                    u[j] = f2bf(round_bf16(b * cf) + round_bf16(-a * sf));
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    t[j] = f2bf(acc[dt][4 * g + j]);
-                    u[j] = f2bf(acc[dt + 2][4 * g + j]);
-                }
-            }
-            *reinterpret_cast<bf16x4*>(dst + d) = t;
-            *reinterpret_cast<bf16x4*>(dst + d + 64) = u;
-        }
-}
-
-
-// Plain store of a gradient row fragment for any head_dim (acc[dt][4g+j] <-> d = dt*32 + 8g + 4*hl + j).
-template <int NDT>
-__device__ __forceinline__ void store_grad_row_plain(bf16* dst, const f32x16 (&acc)[NDT], int hl) {
-#pragma unroll
-    for (int dt = 0; dt < NDT; ++dt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            bf16x4 t;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) t[j] = f2bf(acc[dt][4 * g + j]);
-            *reinterpret_cast<bf16x4*>(dst + dt * 32 + 8 * g + 4 * hl) = t;
-        }
-}
-
-struct AttnArgs {
-    const bf16* q;
-    const bf16* k;
-    const bf16* v;
-    int ld;  // row stride of q/k/v (elements)
-    bf16* o;
-    int ldo;
-    float* lse;        // [B][H][S] natural-log lse of the scaled scores (+inf for rows with no valid key)
-    const int* kmask;  // [B][S] 1 = attend, 0 = masked key; may be null
-    int B, S, H;
-    float scale;
-    // backward
-    const bf16* dout;
-    int lddo;
-    const float* delta;  // [B][H][S]
-    bf16* dq;
-    bf16* dk;
-    bf16* dv;
-    int ldg;  // row stride of dq/dk/dv
-    // optional fused inverse RoPE on the dq / dk stores (head_dim 128): positions [B*S], tables [n_pos][64] bf16
-    const int* rope_pos;
-    const bf16* rope_cos;
-    const bf16* rope_sin;
-};
 
 // ------------------------------------------------------------------------------------------------
 // Forward. grid (ceil(S/128), H, B), 256 threads; wave w owns query rows qb*128 + 32w .. +31.
 // LDS: 2 x (K tile 64xD | V tile 64xD) + 2 x 64 floats key bias.
 // ------------------------------------------------------------------------------------------------
-// Workgroup -> (tile, head, batch) for a 1-D grid of nx * H * B workgroups.  The hardware deals consecutive workgroup
-// ids round-robin over the 8 XCDs (each with its own L2), so with the natural order the nx tiles of one (batch, head)
-// — which all stream the same K / V (or Q / dO) rows — land on 8 different L2s and every one of them fetches that
-// head again.  Here the XCD index (id & 7) selects the (batch, head) pair inside a group of 8 pairs and the remaining
-// bits walk that pair's tiles, so one head's tiles run back to back on ONE XCD and hit in its L2.  Heavy (late, causal)
-// tiles first.  Falls back to the natural order when H * B is not a multiple of 8.
-__device__ __forceinline__ void decode_wg(int nx, int H, int B, bool heavy_is_last, int& tile, int& hh, int& b) {
-    const int w = blockIdx.x, nbh = H * B;
-    int bh, t;
-    if ((nbh & 7) == 0) {
-        const int xcd = w & 7, slot = w >> 3;
-        bh = (slot / nx) * 8 + xcd;
-        t = slot % nx;
-    } else {
-        bh = w / nx;
-        t = w % nx;
-    }
-    tile = heavy_is_last ? nx - 1 - t : t;  // causal: late query tiles / early key tiles carry the most blocks
-    hh = bh % H;
-    b = bh / H;
-}
 
 template <int D, bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
@@ -938,12 +695,6 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
 #endif
 }
 
-template <typename K>
-int set_lds(K kern, int bytes) {
-    hipError_t e =
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    return (int)e;
-}
 
 template <int D, bool CAUSAL>
 int launch_fwd(const AttnArgs& a, hipStream_t s) {
@@ -958,6 +709,8 @@ int launch_fwd(const AttnArgs& a, hipStream_t s) {
     MMU_CHECK_LAUNCH();
     return 0;
 }
+
+static int g_dkdv_variant = 8;  // mmu_attn_set_dkdv_variant: 8 = eight-wave kernel, 4 = four-wave register-resident kernel
 
 template <int D, bool CAUSAL>
 int launch_bwd(const AttnArgs& a, hipStream_t s) {
@@ -975,6 +728,17 @@ int launch_bwd(const AttnArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((attn_delta_kernel<D>), dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, a.o, a.ldo, a.dout,
                        a.lddo, const_cast<float*>(a.delta), a.lse, a.B, a.S, a.H);
     MMU_CHECK_LAUNCH();
+    if constexpr (D == 128) {
+        // 4 waves x 512 registers, persistent, K / V in registers, 4-stage Q/dO ring (attention_dkdv4.hip); its DMA
+        // addressing wants row strides that are multiples of 32 elements
+        if (g_dkdv_variant == 4 && a.ld % 32 == 0 && a.lddo % 32 == 0) {
+            const int e4 = mmu_internal_launch_dkdv4(&a, CAUSAL ? 1 : 0, s);
+            if (e4) return e4;
+            hipLaunchKernelGGL((attn_bwd_dq_kernel<D, CAUSAL>), dim3(((a.S + 127) / 128) * a.H * a.B), dim3(256), LDS_DQ, s, a);
+            MMU_CHECK_LAUNCH();
+            return 0;
+        }
+    }
     hipLaunchKernelGGL((attn_bwd_dkdv_kernel<D, CAUSAL>), dim3(((a.S + 127) / 128) * a.H * a.B), dim3(512), LDS_KV, s, a);
     MMU_CHECK_LAUNCH();
     hipLaunchKernelGGL((attn_bwd_dq_kernel<D, CAUSAL>), dim3(((a.S + 127) / 128) * a.H * a.B), dim3(256), LDS_DQ, s, a);
@@ -1052,3 +816,15 @@ extern "C" int mmu_debug_read_attn_stamps(unsigned long long* host_out, int n_bl
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_attn_stamps), (size_t)n_blocks * 32, 0, hipMemcpyDeviceToHost);
 }
 #endif
+
+// dK/dV kernel of the head_dim-128 backward: 8 = eight waves, K / V tiles in LDS, two partial sums per key group;
+// 4 = four waves with K / V fragments in registers and a 4-stage Q/dO ring.  Process-wide A/B / tuning switch.
+// Bits 8 and up: workgroups of the persistent four-wave kernel (0 = one per CU, else a multiple of 8; the tests use a
+// small grid so that every workgroup crosses item seams).
+extern "C" int mmu_attn_set_dkdv_variant(int v) {
+    const int kind = v & 255, grid = v >> 8;
+    if (v < 0 || (kind != 4 && kind != 8)) return -1;
+    if (mmu_internal_set_dkdv4_grid(grid)) return -1;
+    g_dkdv_variant = kind;
+    return 0;
+}

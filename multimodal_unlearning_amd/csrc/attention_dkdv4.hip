@@ -1,0 +1,532 @@
+// Four-wave, register-resident, persistent dK/dV kernel of the head_dim-128 attention backward (see the comment above
+// the kernel).  A translation unit of its own: it is the one kernel that owns the whole 512-entry register file.
+#include "attention_common.h"
+
+namespace {
+
+// LDS-DMA issued from inline asm (guide §5.7): hipcc does not see these loads, so it inserts no `s_waitcnt vmcnt(0)` in
+// front of later LDS reads (with the builtin form it drains the whole ring before every transposed read: the run-ahead
+// would be lost).  Completion is counted by hand: `s_waitcnt vmcnt(N)` + s_barrier at the top of a step.
+// M0 (the DMA's LDS base) is written and restored inside the statement.
+// Per-lane address form (ragged stages: rows past the sequence are clamped / redirected per lane)
+__device__ __forceinline__ void glds16_asm(const void* gsrc, unsigned lds_wave_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_wave_base)
+                 : "memory");
+}
+__device__ __forceinline__ void glds4_asm(const void* gsrc, unsigned lds_wave_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_wave_base)
+                 : "memory");
+}
+// Scalar base + 32-bit per-lane byte offset (the steady state: one VGPR per piece, no 64-bit address arithmetic)
+__device__ __forceinline__ void glds16_sv(const void* sbase, unsigned voff, unsigned lds_wave_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_wave_base)
+                 : "memory");
+}
+__device__ __forceinline__ void glds4_sv(const void* sbase, unsigned voff, unsigned lds_wave_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_wave_base)
+                 : "memory");
+}
+
+// s_waitcnt immediates (gfx9 layout: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] at [15:14])
+constexpr int waitcnt_vm(int n) { return (n & 15) | ((n >> 4) << 14) | 0x0F70; }
+
+// ------------------------------------------------------------------------------------------------
+// dK / dV, round-2 structure (head_dim 128): 256 threads = 4 waves, ONE wave per SIMD with the whole 512-entry
+// register file, one PERSISTENT workgroup per CU walking the (key block, head, batch) items  v = blockIdx.x,
+// blockIdx.x + gridDim.x, ...  (gridDim.x is a multiple of 8, so the item -> XCD map of decode_wg_at — one head's key
+// blocks on one XCD's L2 — is the same as for a one-item-per-workgroup launch, and because 5 k mod 9 walks all key
+// blocks every workgroup gets the same mix of long and short causal sweeps).
+// Wave w owns keys kvb*128 + 32w .. +31 for a whole item ("key on the lane"): its K and V fragments (the B operands
+// of S = Q K^T and dP = dO V^T) are loaded once per item, straight from global memory, and stay in registers (64); its
+// dK^T / dV^T accumulators (128, AGPRs) need no cross-wave reduction; no K / V tile lives in LDS.
+// The LDS holds only a 4-stage ring of 64-row (Q | dO | lse2, delta) stages filled by LDS-DMA three STEPS ahead, and
+// the ring runs across item seams: while an item's last steps and its stores run, the first stages of the next item
+// are already landing, so there is no per-item prologue (measured on the one-item-per-workgroup version of this
+// kernel: prologue 8.7 k + store tail 10.6 k cycles of a 69 k-cycle average workgroup, tools/attn_stamps.py --dkdv4).
+// The nine DMA pieces a wave contributes to a stage are issued at the boundaries of the MFMA regions of a step, not
+// in a burst at its top; the next item's K / V fragments are requested before the current item's stores are issued
+// and are waited for by count.
+// Per 32-row query tile four scheduling regions of 8 MFMAs each carry the LDS reads of a later region and the VALU
+// work of an earlier one (sched_group_barrier), see `tile` below.
+// Measured reason for the rebuild (tools/attn_stamps.py on the 8-wave kernel): 5 850 cycles per iteration for 2 x 1 024
+// cycles of MFMA issue per SIMD, an epilogue worth 2.3 iterations (cross-wave partial sums through 128 KiB of LDS),
+// one workgroup per CU meeting at a barrier with the next stage only one iteration ahead.
+// ------------------------------------------------------------------------------------------------
+#ifndef DKDV4_EXP  // timing experiments only (tools/attn_stamps.py): 1 no in-step DMA, 2 no softmax VALU, 4 no transposed
+#define DKDV4_EXP 0  // LDS reads, 8 no stores, 16 no row LDS reads — results are garbage, addresses unchanged
+#endif
+constexpr int DKDV4_STAGES = 4;
+constexpr int DKDV4_STORES = 16;  // global stores per wave and item (8 x 16 B per lane for dK, 8 for dV)
+
+template <bool CAUSAL>
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkdv4_kernel(AttnArgs a, int n_items) {
+    constexpr int D = 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TB = 64 * D * 2;             // one 64-row tile (Q or dO): 16 KiB
+    constexpr int STB = 2 * TB;                // Q | dO of one stage: 32 KiB
+    constexpr int ROWC = DKDV4_STAGES * STB;   // row constants: [stage][lse2 64 | delta 64] floats
+    constexpr int NKS = D / 16, NDT = D / 32, NST = DKDV4_STAGES;
+    STAMP(t_start);
+#ifdef MMU_ATTN_STAMP
+    unsigned long long t_vm = 0, t_bar = 0, t_clean = 0, n_clean = 0, t_epi = 0, n_it = 0, n_steps = 0;
+#endif
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int hl = lane >> 5;
+    const int S = a.S, G = gridDim.x;
+    const int nx = (S + 127) / 128;
+    if ((int)blockIdx.x >= n_items) return;
+
+    // per-lane fragment offsets inside a stage's Q tile (query tile 0; tile 1 = + 32 rows, dO = + TB: immediates)
+    int off_row[NKS], off_tr1[NDT], off_tr2[NDT];
+    {
+        const int r = lane & 31;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) off_row[ks] = r * (D * 2) + (((2 * ks + hl) ^ swz<D, KIND_ROW>(r)) << 4);
+        const int g = lane >> 4, gb = g & 1, h = g >> 1, i = lane & 15, q = i >> 2, pp = i & 3;
+        const int r1 = 4 * h + q, r2 = r1 + 8, sub = (pp & 1) << 3;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+            const int ch = 4 * dt + 2 * gb + (pp >> 1);
+            off_tr1[dt] = r1 * (D * 2) + ((ch ^ swz<D, KIND_ROW>(r1)) << 4) + sub;
+            off_tr2[dt] = r2 * (D * 2) + ((ch ^ swz<D, KIND_ROW>(r2)) << 4) + sub;
+        }
+    }
+    // per-lane byte offset inside one 1-KiB piece of a 64-row tile (4 rows of 16 swizzled 16-B chunks): piece t of this wave
+    // covers rows (4 wave + t) * 4 .. + 3; the row part of a piece goes into its scalar base, and because the swizzle of
+    // row r is ((r & 3) << 2) | ((r >> 2) & 3) the pieces differ only by chunk ^ t, i.e. byte offset ^ 16 t (the row
+    // strides are multiples of 32 elements — checked by the launcher — so bits 4, 5 of the offset are the chunk's)
+    const unsigned q_off0 = (unsigned)((lane >> 4) * a.ld + ((lane & 15) ^ ((lane >> 4) << 2)) * 8) * 2u;
+    const unsigned do_off0 = (unsigned)((lane >> 4) * a.lddo + ((lane & 15) ^ ((lane >> 4) << 2)) * 8) * 2u;
+    const unsigned lds_base = (unsigned)(uintptr_t)(MMU_LDS char*)smem;
+    const float c = a.scale * LOG2E;
+
+    // ---- the DMA cursor: the stage that is issued next (all wave-uniform).  Past the last stage of the last item it
+    // stays where it is: the pieces then re-read that stage into a ring slot nobody reads, which keeps the issue and the
+    // counted waits free of branches.
+    int d_item = blockIdx.x, d_pr, d_pr1, issued = 0;
+    const bf16* d_q;
+    const bf16* d_do;
+    const float* d_lse;
+    const float* d_dl;
+    auto dma_open = [&](int v) {
+        int kvb, hh, b;
+        decode_wg_at(v, nx, a.H, a.B, false, kvb, hh, b);
+        const size_t rowbase = (size_t)b * S;
+        d_q = a.q + rowbase * a.ld + hh * D;
+        d_do = a.dout + rowbase * a.lddo + hh * D;
+        d_lse = a.delta + ((size_t)a.B * a.H + (size_t)b * a.H + hh) * S;  // lse * log2(e)
+        d_dl = a.delta + ((size_t)b * a.H + hh) * S;
+        d_pr = CAUSAL ? kvb * 2 : 0;
+        d_pr1 = (S + 63) / 64;
+    };
+    dma_open(d_item);
+    // piece p (0..3 Q, 4..7 dO, 8 row constants) of the cursor's stage
+    auto dma_piece = [&](int p) {
+        const unsigned slot = lds_base + (issued % NST) * STB;
+        const int row0 = d_pr * 64;
+        const bool full = row0 + 64 <= S;
+        if (p < 8) {
+            const int t = p & 3;
+            const bool is_do = p >= 4;
+            const int ld = is_do ? a.lddo : a.ld;
+            const int prow = (wave * 4 + t) * 4;  // first row of the piece inside the tile
+            const unsigned dst = slot + (is_do ? TB : 0) + (wave * 4 + t) * 1024;
+            const bf16* base;
+            unsigned off;
+            if (full) {
+                base = (is_do ? d_do : d_q) + (size_t)(row0 + prow) * ld;
+                off = (is_do ? do_off0 : q_off0) ^ (unsigned)(t << 4);
+            } else {  // rows past the sequence re-read row S-1 (their lse2 is +inf: P = 0 exactly)
+                base = (is_do ? d_do : d_q) + (size_t)row0 * ld;
+                const int row = min(prow + (lane >> 4), S - 1 - row0);
+                off = (unsigned)(row * ld) * 2u + (unsigned)((((lane & 15) ^ ((lane >> 4) << 2)) ^ t) << 4);
+            }
+            glds16_sv(base, off, __builtin_amdgcn_readfirstlane(dst));
+        } else if (lane < 32) {  // waves 0,1: lse2 rows [0,32) / [32,64); waves 2,3: delta rows likewise
+            const int qr = row0 + (wave & 1) * 32 + lane;
+            const unsigned dst = lds_base + ROWC + ((issued % NST) * 128 + (wave >> 1) * 64 + (wave & 1) * 32) * 4;
+            if (full) {
+                glds4_sv((wave < 2 ? d_lse : d_dl) + row0 + (wave & 1) * 32, (unsigned)lane * 4u,
+                         __builtin_amdgcn_readfirstlane(dst));
+            } else {
+                const float* src = wave < 2 ? (qr < S ? d_lse + qr : reinterpret_cast<const float*>(mmu_inf16))
+                                            : (qr < S ? d_dl + qr : reinterpret_cast<const float*>(mmu_zero16));
+                glds4_asm(src, __builtin_amdgcn_readfirstlane(dst));
+            }
+        }
+    };
+    auto dma_advance = [&]() {
+        ++issued;
+        if (d_pr + 1 < d_pr1) ++d_pr;
+        else if (d_item + G < n_items) { d_item += G; dma_open(d_item); }
+    };
+    bool in_steps = false;
+    auto dma_pieces = [&](int p0, int n) {
+#pragma unroll
+        for (int p = p0; p < p0 + n; ++p)
+            if (!((DKDV4_EXP & 1) && in_steps)) dma_piece(p);
+        if (p0 + n == 9) dma_advance();
+    };
+#pragma unroll
+    for (int i = 0; i < NST - 1; ++i) dma_pieces(0, 9);
+
+    // ---- item state of the compute side
+    int kvb, hh, b;
+    decode_wg_at(blockIdx.x, nx, a.H, a.B, false, kvb, hh, b);
+    // K / V fragments of this wave's 32 keys: lane (key, hl) holds K[key][16 ks + 8 hl .. +7] (B operand map).  Keys past
+    // the sequence re-read row S-1 (their P is masked to 0, the operands only have to be finite).
+    bf16x8 kf[NKS], vf[NKS];
+    bool kvalid;
+    auto load_kv = [&](int kvb_, int hh_, int b_) {
+        const size_t rowbase = (size_t)b_ * S;
+        const int key = kvb_ * 128 + wave * 32 + (lane & 31);
+        const size_t krow = (rowbase + (key < S ? key : S - 1)) * a.ld + hh_ * D + 8 * hl;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            kf[ks] = *reinterpret_cast<const bf16x8*>(a.k + krow + 16 * ks);
+            vf[ks] = *reinterpret_cast<const bf16x8*>(a.v + krow + 16 * ks);
+        }
+        kvalid = key < S && (a.kmask == nullptr || a.kmask[rowbase + key] != 0);
+    };
+    load_kv(kvb, hh, b);
+    // the modelled wait tells the compiler that these loads have landed, or it would re-check them with
+    // s_waitcnt vmcnt(..0) inside the step loop and drain the ring with it
+    __builtin_amdgcn_s_waitcnt(waitcnt_vm(0));
+
+    f32x16 dk[NDT], dv[NDT];
+    in_steps = true;
+    const MMU_LDS char* lds0 = (const MMU_LDS char*)smem;
+    int gs = 0;  // steps done by this workgroup = index of the stage the next step reads
+
+    for (int item = blockIdx.x; item < n_items; item += G) {
+        const int key0 = kvb * 128 + wave * 32;
+        const int key = key0 + (lane & 31);
+        const bool all_valid = __all(kvalid);
+        const size_t rowbase = (size_t)b * S;
+#pragma unroll
+        for (int i = 0; i < NDT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { dk[i][r] = 0.f; dv[i][r] = 0.f; }
+        const int pr0 = CAUSAL ? kvb * 2 : 0;
+        const int pr1 = (S + 63) / 64;
+
+        for (int pr = pr0; pr < pr1; ++pr, ++gs) {
+            const int buf = gs % NST;
+            // stage `gs` has landed when at most the pieces of the stages issued after it are outstanding
+            const int ahead = issued - 1 - gs;
+            STAMP(t_w0);
+            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            STAMP(t_w1);
+            __builtin_amdgcn_s_barrier();  // every wave's pieces of stage `gs` are in LDS; slot (gs-1)%NST is free
+            STAMP(t_w2);
+#ifdef MMU_ATTN_STAMP
+            t_vm += t_w1 - t_w0;
+            t_bar += t_w2 - t_w1;
+            n_steps += 1;
+#endif
+            const MMU_LDS char* qt = lds0 + buf * STB;  // wave-uniform stage base (one scalar add per address below)
+            const MMU_LDS float* rc = (const MMU_LDS float*)(smem + ROWC) + buf * 128;
+            const bool act0 = pr * 64 < S && (!CAUSAL || (pr * 64 + 31 >= key0));
+            const bool act1 = pr * 64 + 32 < S && (!CAUSAL || (pr * 64 + 63 >= key0));
+#define SB() __builtin_amdgcn_sched_barrier(0)
+#define SG(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+            // Q row fragments and lse2 of a tile (requested one region ahead of its S chain)
+            auto load_rows = [&](int half, bf16x8(&fq)[NKS], f32x4(&l)[4]) {
+                const MMU_LDS char* qtile = qt + half * 32 * (D * 2);
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks)
+                    if (!(DKDV4_EXP & 16)) fq[ks] = *(const MMU_LDS bf16x8*)(qtile + off_row[ks]);
+                    else fq[ks] = vf[ks];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) l[g] = *(const MMU_LDS f32x4*)(rc + half * 32 + 8 * g + 4 * hl);
+            };
+            // One 32-row query tile against this wave's 32 keys, four scheduling regions of 8 MFMAs each; every region
+            // carries the LDS reads of a LATER region and the VALU work of an EARLIER one between its MFMAs:
+            //   R1  S = Q K^T chain          | transposed dO^T, Q^T fragments of rows 0..15, dO row fragments
+            //   R2  dP = dO V^T chain        | P = exp2(S c - lse2), its bf16 fragments | transposed fragments, rows 16..31, delta
+            //   R3  dV^T += dO^T P           | dS = P (dP - delta) and its bf16 fragments
+            //   R4  dK^T += Q^T dS           | Q row fragments + lse2 of the NEXT tile (next >= 0)
+            // DMA pieces p0 .. p0+np-1 of the stage three steps ahead go out at the region boundaries.
+            // MASKED: causal diagonal / padded keys: rows below `kd2 + 4 hl` (per lane) get P = 0.
+            auto tile = [&](auto masked_c, int half, int next, int p0, int np, bf16x8(&fq)[NKS], f32x4(&l)[4]) {
+                constexpr bool MASKED = decltype(masked_c)::value;
+                const MMU_LDS char* qtile = qt + half * 32 * (D * 2);
+                bf16x8 to[NDT], tq[NDT], to2[NDT], tq2[NDT], fo[NKS];
+                f32x4 d[4];
+                f32x16 sv, dpv;
+                int kd2 = 0;
+                if (MASKED) {
+                    const int q_first = pr * 64 + half * 32;
+                    const bool diag = CAUSAL && (q_first < key0 + 31);
+                    kd2 = !kvalid ? 1000 : (diag ? key - q_first - 4 * hl : -1000);  // row 8g+j masked iff 8g+j < kd2
+                }
+                const int n1 = np > 0 ? 1 : 0, n2 = np > 1 ? 1 : 0, n3 = np > 2 ? 1 : 0, n4 = np > 3 ? np - 3 : 0;
+                dma_pieces(p0, n1);
+                // ---- R1
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sv[r] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) sv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[ks], kf[ks], sv, 0, 0, 0);
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) {
+                    if (DKDV4_EXP & 4) { to[dt] = kf[dt]; tq[dt] = vf[dt]; continue; }
+                    to[dt] = tr_load(qtile + TB + off_tr1[dt], qtile + TB + off_tr2[dt]);
+                    tq[dt] = tr_load(qtile + off_tr1[dt], qtile + off_tr2[dt]);
+                }
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks)
+                    if (!(DKDV4_EXP & 16)) fo[ks] = *(const MMU_LDS bf16x8*)(qtile + TB + off_row[ks]);
+                    else fo[ks] = kf[ks];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { SG(0x8, 1); SG(0x100, 3); }
+                SB();
+                dma_pieces(p0 + n1, n2);
+                // ---- R2
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dpv[r] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) dpv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fo[ks], vf[ks], dpv, 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (DKDV4_EXP & 2) continue;
+                        const float pv = fast_exp2(__builtin_fmaf(sv[4 * g + j], c, -l[g][j]));
+                        sv[4 * g + j] = (MASKED && (8 * g + j < kd2)) ? 0.f : pv;
+                    }
+                const bf16x8 pf = pack8(sv, 0), pf2 = pack8(sv, 1);
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) {
+                    if (DKDV4_EXP & 4) { to2[dt] = kf[4 + dt]; tq2[dt] = vf[4 + dt]; continue; }
+                    to2[dt] = tr_load(qtile + 16 * (D * 2) + TB + off_tr1[dt], qtile + 16 * (D * 2) + TB + off_tr2[dt]);
+                    tq2[dt] = tr_load(qtile + 16 * (D * 2) + off_tr1[dt], qtile + 16 * (D * 2) + off_tr2[dt]);
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) d[g] = *(const MMU_LDS f32x4*)(rc + 64 + half * 32 + 8 * g + 4 * hl);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { SG(0x8, 1); SG(0x100, 3); SG(0x2, MASKED ? 10 : 7); }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { SG(0x8, 1); SG(0x100, 2); SG(0x2, MASKED ? 10 : 7); }
+                SB();
+                dma_pieces(p0 + n1 + n2, n3);
+                // ---- R3
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(to[dt], pf, dv[dt], 0, 0, 0);
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(to2[dt], pf2, dv[dt], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (!(DKDV4_EXP & 2)) dpv[4 * g + j] = sv[4 * g + j] * (dpv[4 * g + j] - d[g][j]);
+                const bf16x8 dsf = pack8(dpv, 0), dsf2 = pack8(dpv, 1);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { SG(0x8, 1); SG(0x2, 5); }
+                SB();
+                dma_pieces(p0 + n1 + n2 + n3, n4);
+                // ---- R4
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tq[dt], dsf, dk[dt], 0, 0, 0);
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tq2[dt], dsf2, dk[dt], 0, 0, 0);
+                if (next >= 0) {
+                    load_rows(next, fq, l);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { SG(0x8, 1); SG(0x100, 2); }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { SG(0x8, 1); SG(0x100, 1); }
+                }
+                SB();
+            };
+            bf16x8 fq[NKS];
+            f32x4 l4[4];
+            const bool clean = all_valid && !(CAUSAL && pr * 64 < key0 + 31) && pr * 64 + 32 < S;
+            if (clean) {  // both tiles active, nothing masked: the steady state
+                load_rows(0, fq, l4);
+                SB();
+                tile(std::false_type{}, 0, 1, 0, 5, fq, l4);
+                tile(std::false_type{}, 1, -1, 5, 4, fq, l4);
+#ifdef MMU_ATTN_STAMP
+                t_clean += stamp_now() - t_w2;
+                n_clean += 1;
+#endif
+            } else {
+                dma_pieces(0, 9);
+                for (int half = 0; half < 2; ++half) {
+                    if (!(half ? act1 : act0)) continue;
+                    load_rows(half, fq, l4);
+                    SB();
+                    tile(std::true_type{}, half, -1, 0, 0, fq, l4);
+                }
+            }
+#undef SB
+#undef SG
+        }
+
+        // ---- the item's gradients: scale dK, transpose rotation of RoPE on the (d, d+64) pairs of dK (same arithmetic
+        // as rope_kernel(inverse=1) on the bf16-rounded gradient), bf16, and 16-B stores: lane (key, hl) holds
+        // d = 32 dt + 8 g + 4 hl + j; one v_permlane32_swap per dword trades the odd-g words of the hl = 0 lanes for the
+        // even-g words of the hl = 1 lanes, so every lane ends up with 8 consecutive d of its key.
+        STAMP(t_e0);
+        const int out_key = key;
+        const size_t out_row = rowbase + key;
+        const int out_hh = hh;
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        u32x2 wk[NDT][4], wv[NDT][4];  // bf16x4 words of dK / dV per (dt, g)
+        {
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dk[dt][r] *= a.scale;
+            if (a.rope_pos) {
+                const int pos = out_key < S ? a.rope_pos[out_row] : 0;
+                const bf16* cr = a.rope_cos + (size_t)pos * 64;
+                const bf16* sr = a.rope_sin + (size_t)pos * 64;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int d = dt * 32 + 8 * g + 4 * hl;  // < 64
+                        const bf16x4 c4 = *reinterpret_cast<const bf16x4*>(cr + d);
+                        const bf16x4 s4 = *reinterpret_cast<const bf16x4*>(sr + d);
+                        bf16x4 t, u;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float x = round_bf16(dk[dt][4 * g + j]), y = round_bf16(dk[dt + 2][4 * g + j]);
+                            const float cf = bf2f(c4[j]), sf = bf2f(s4[j]);
+                            t[j] = f2bf(round_bf16(x * cf) + round_bf16(y * sf));
+                            u[j] = f2bf(round_bf16(y * cf) + round_bf16(-x * sf));
+                        }
+                        wk[dt][g] = __builtin_bit_cast(u32x2, t);
+                        wk[dt + 2][g] = __builtin_bit_cast(u32x2, u);
+                    }
+            } else {
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        bf16x4 t;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) t[j] = f2bf(dk[dt][4 * g + j]);
+                        wk[dt][g] = __builtin_bit_cast(u32x2, t);
+                    }
+            }
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    bf16x4 t;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) t[j] = f2bf(dv[dt][4 * g + j]);
+                    wv[dt][g] = __builtin_bit_cast(u32x2, t);
+                }
+        }
+        // the next item's K / V (and key mask) are requested BEFORE this item's stores go out; the wait in front of the
+        // next item's first step then only has to leave the stores outstanding
+        const bool more = item + G < n_items;
+        if (more) {
+            decode_wg_at(item + G, nx, a.H, a.B, false, kvb, hh, b);
+            load_kv(kvb, hh, b);
+        }
+        const bool stores = key0 < S;  // wave-uniform
+        if (out_key < S && !(DKDV4_EXP & 8)) {
+            bf16* dkp = a.dk + out_row * a.ldg + out_hh * D;
+            bf16* dvp = a.dv + out_row * a.ldg + out_hh * D;
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    u32x4 ok, ov;
+#pragma unroll
+                    for (int w = 0; w < 2; ++w) {
+                        // x = words of g = 2m (kept by hl = 0), y = words of g = 2m+1 (kept by hl = 1)
+                        auto sk = __builtin_amdgcn_permlane32_swap(wk[dt][2 * m][w], wk[dt][2 * m + 1][w], false, false);
+                        auto sv2 = __builtin_amdgcn_permlane32_swap(wv[dt][2 * m][w], wv[dt][2 * m + 1][w], false, false);
+                        ok[w] = sk[0]; ok[2 + w] = sk[1];
+                        ov[w] = sv2[0]; ov[2 + w] = sv2[1];
+                    }
+                    const int d = dt * 32 + 16 * m + 8 * hl;
+                    *reinterpret_cast<u32x4*>(dkp + d) = ok;
+                    *reinterpret_cast<u32x4*>(dvp + d) = ov;
+                }
+        }
+        if (more) {
+            if (stores) __builtin_amdgcn_s_waitcnt(waitcnt_vm(DKDV4_STORES));
+            else __builtin_amdgcn_s_waitcnt(waitcnt_vm(0));
+        }
+#ifdef MMU_ATTN_STAMP
+        t_epi += stamp_now() - t_e0;
+        n_it += 1;
+#endif
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the phantom stages behind the last step
+#ifdef MMU_ATTN_STAMP
+    {
+        const unsigned long long t_end = stamp_now();
+        if (threadIdx.x == 0 && blockIdx.x < 8192) {
+            unsigned long long* o = g_attn_stamps + 8 * blockIdx.x;
+            o[0] = n_it; o[1] = n_steps; o[2] = t_vm; o[3] = t_bar;
+            o[4] = t_end - t_start; o[5] = t_epi; o[6] = t_clean; o[7] = n_clean;
+        }
+    }
+#endif
+}
+
+int g_dkdv4_grid = 0;  // 0 = one workgroup per CU
+
+}  // namespace
+
+#ifdef MMU_ATTN_STAMP
+extern "C" int mmu_debug_read_dkdv4_stamps(unsigned long long* host_out, int n_blocks) {
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_attn_stamps), (size_t)n_blocks * 64, 0, hipMemcpyDeviceToHost);
+}
+#endif
+
+int mmu_internal_set_dkdv4_grid(int n) {
+    if (n < 0 || (n & 7)) return 1;  // multiples of 8 keep the item -> XCD map
+    g_dkdv4_grid = n;
+    return 0;
+}
+
+int mmu_internal_launch_dkdv4(const void* attn_args, int causal, hipStream_t stream) {
+    const AttnArgs& a = *reinterpret_cast<const AttnArgs*>(attn_args);
+    constexpr int LDS4 = DKDV4_STAGES * (2 * 64 * 128 * 2) + DKDV4_STAGES * 128 * 4;
+    static bool cfg[2] = {false, false};
+    static int n_cu = 0;
+    if (!cfg[causal ? 1 : 0]) {
+        int e = causal ? set_lds(attn_bwd_dkdv4_kernel<true>, LDS4) : set_lds(attn_bwd_dkdv4_kernel<false>, LDS4);
+        if (e) return e;
+        cfg[causal ? 1 : 0] = true;
+    }
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 1;
+        n_cu = prop.multiProcessorCount;
+    }
+    const int n_items = ((a.S + 127) / 128) * a.H * a.B;
+    int g = g_dkdv4_grid ? g_dkdv4_grid : (n_cu & ~7);
+    if (g > n_items) g = (n_items + 7) & ~7;
+    const dim3 grid(g);
+    if (causal) hipLaunchKernelGGL((attn_bwd_dkdv4_kernel<true>), grid, dim3(256), LDS4, stream, a, n_items);
+    else hipLaunchKernelGGL((attn_bwd_dkdv4_kernel<false>), grid, dim3(256), LDS4, stream, a, n_items);
+    MMU_CHECK_LAUNCH();
+    return 0;
+}

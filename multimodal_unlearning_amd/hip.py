@@ -36,6 +36,7 @@ SIGNATURES = {
                      _vp],
     "mmu_attn_bwd_rope": [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i,
                           _vp, _vp, _vp, _vp],
+    "mmu_attn_set_dkdv_variant": [_i],
     "mmu_rmsnorm_fwd": [_vp, _vp, _vp, _vp, _i, _i, _f, _vp],
     "mmu_rmsnorm_bwd_nparts": [_i],
     "mmu_rmsnorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
@@ -257,6 +258,15 @@ def attn_bwd(q, k, v, o, lse, kmask, dout, delta, dq, dk, dv, B, S, H, head_dim,
                                   dout.stride(0), _p(delta), _p(dq), _p(dk), _p(dv), dq.stride(0), B, S, H, head_dim,
                                   float(scale), int(causal), _p(pos), _p(ct), _p(st), _stream())
     _check(rc, "mmu_attn_bwd_rope")
+
+
+DKDV_DEFAULT = 8
+
+
+def attn_set_dkdv_variant(v: int, grid: int = 0):
+    """8 = eight-wave dK/dV kernel; 4 = four-wave persistent register-resident kernel (head_dim 128) on `grid`
+    workgroups (0 = one per CU, else a multiple of 8)."""
+    _check(load().mmu_attn_set_dkdv_variant(int(v) | (int(grid) << 8)), "mmu_attn_set_dkdv_variant")
 
 
 # ------------------------------------------------------------------------------------------------ norms

@@ -42,6 +42,7 @@ GEMM_SHAPES = [(128, 128, 64), (256, 384, 192), (300, 136, 200), (77, 8, 24), (2
 def _reset_tile():
     yield
     hip.gemm_set_tile(0)
+    hip.attn_set_dkdv_variant(hip.DKDV_DEFAULT)
 
 
 @pytest.mark.parametrize("tile", [128, 256])
@@ -188,8 +189,16 @@ def test_attn_fwd_left_pad_mask(dev):
 
 @pytest.mark.parametrize("B,H,S,causal,pad,D", [(1, 1, 64, True, 0, 128), (2, 2, 200, True, 0, 128), (1, 2, 1088, True, 0, 128),
                                                 (2, 2, 333, False, 0, 128), (2, 2, 150, True, 20, 128),
-                                                (2, 3, 577, False, 0, 64), (1, 2, 130, True, 0, 64), (2, 2, 70, False, 9, 64)])
-def test_attn_bwd(dev, B, H, S, causal, pad, D):
+                                                (2, 3, 577, False, 0, 64), (1, 2, 130, True, 0, 64), (2, 2, 70, False, 9, 64),
+                                                (2, 4, 333, True, 0, 128), (1, 8, 1088, True, 0, 128),
+                                                (3, 8, 300, True, 37, 128), (2, 8, 450, False, 0, 128)])
+@pytest.mark.parametrize("variant", [(8, 0), (4, 0), (4, 8)], ids=["w8", "w4", "w4-grid8"])
+def test_attn_bwd(dev, B, H, S, causal, pad, D, variant):
+    # (4, 8): the persistent four-wave kernel on 8 workgroups, so every workgroup walks several items (seams, ring
+    # run-ahead across items, counted waits behind the stores)
+    if variant[0] == 4 and D != 128:
+        pytest.skip("the four-wave dK/dV kernel is a head_dim-128 kernel")
+    hip.attn_set_dkdv_variant(*variant)
     g = torch.Generator().manual_seed(S)
     q, k, v, do = (torch.randn(B, H, S, D, generator=g).to(dev).to(BF) for _ in range(4))
     kmask = None
@@ -598,14 +607,16 @@ def test_fused_rope_epilogue_and_bwd_store(dev):
     hip.attn_fwd(qkv[:, :dt], qkv[:, dt:2 * dt], qkv[:, 2 * dt:], o, lse, None, B, S, H, D, sc, True)
     do = _randn((M, dt), dev, 1.0, 3)
     delta = torch.empty(2, B, H, S, device=dev, dtype=torch.float32)
-    d1 = torch.empty(M, 3 * dt, device=dev, dtype=BF)
-    hip.attn_bwd(qkv[:, :dt], qkv[:, dt:2 * dt], qkv[:, 2 * dt:], o, lse, None, do, delta, d1[:, :dt], d1[:, dt:2 * dt],
-                 d1[:, 2 * dt:], B, S, H, D, sc, True)
-    hip.rope(d1, pos, cos_t, sin_t, H, H, D, dt, inverse=True)
-    d2 = torch.empty_like(d1)
-    hip.attn_bwd(qkv[:, :dt], qkv[:, dt:2 * dt], qkv[:, 2 * dt:], o, lse, None, do, delta, d2[:, :dt], d2[:, dt:2 * dt],
-                 d2[:, 2 * dt:], B, S, H, D, sc, True, rope=(pos, cos_t, sin_t))
-    assert torch.equal(d2, d1)
+    for variant in ((8, 0), (4, 0), (4, 8)):  # both dK/dV kernels; (4, 8): one workgroup walks several items
+        hip.attn_set_dkdv_variant(*variant)
+        d1 = torch.empty(M, 3 * dt, device=dev, dtype=BF)
+        hip.attn_bwd(qkv[:, :dt], qkv[:, dt:2 * dt], qkv[:, 2 * dt:], o, lse, None, do, delta, d1[:, :dt],
+                     d1[:, dt:2 * dt], d1[:, 2 * dt:], B, S, H, D, sc, True)
+        hip.rope(d1, pos, cos_t, sin_t, H, H, D, dt, inverse=True)
+        d2 = torch.empty_like(d1)
+        hip.attn_bwd(qkv[:, :dt], qkv[:, dt:2 * dt], qkv[:, 2 * dt:], o, lse, None, do, delta, d2[:, :dt],
+                     d2[:, dt:2 * dt], d2[:, 2 * dt:], B, S, H, D, sc, True, rope=(pos, cos_t, sin_t))
+        assert torch.equal(d2, d1), variant
 
 
 @pytest.mark.parametrize("layout", [hip.NT, hip.TN])

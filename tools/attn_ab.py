@@ -6,7 +6,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from multimodal_unlearning_amd import hip
 
+# LIB or LIB:VARIANT (dK/dV kernel variant 8 / 4 of that library)
 la, lb = sys.argv[1], sys.argv[2]
+var = {}
+for tag, spec in (("A", la), ("B", lb)):
+    if ":" in spec:
+        spec, v = spec.rsplit(":", 1)
+        var[tag] = int(v)
+    if tag == "A": la = spec
+    else: lb = spec
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 30
 H, S, D = 32, 1088, 128
 dev = torch.device("cuda:0")
@@ -16,6 +24,8 @@ for tag, path in (("A", la), ("B", lb)):
     for n in ("mmu_attn_fwd", "mmu_attn_bwd_rope"):
         f = getattr(lib, n); f.argtypes = hip.SIGNATURES[n]; f.restype = C.c_int
     libs[tag] = lib
+    if tag in var:
+        lib.mmu_attn_set_dkdv_variant.argtypes = [C.c_int]; lib.mmu_attn_set_dkdv_variant.restype = C.c_int
 g = torch.Generator(device=dev).manual_seed(0)
 HD = H * D
 qkv = torch.randn(B * S, 3 * HD, device=dev, generator=g).bfloat16()
@@ -33,6 +43,8 @@ def fwd(tag):
     assert rc == 0, rc
 def bwd(tag):
     o = out[tag]
+    if tag in var:
+        assert libs[tag].mmu_attn_set_dkdv_variant(var[tag]) == 0
     d = o["dqkv"]
     rc = libs[tag].mmu_attn_bwd_rope(p(qkv), p(qkv) + 2 * HD, p(qkv) + 4 * HD, 3 * HD, p(o["o"]), HD, p(o["lse"]), 0, p(do), HD,
                                      p(o["delta"]), p(d), p(d) + 2 * HD, p(d) + 4 * HD, 3 * HD, B, S, H, D, sc, 1, 0, 0, 0, st())

@@ -5,7 +5,7 @@ Usage: python tools/attn_stamps.py [B]"""
 import ctypes as C, os, statistics, subprocess, sys, math
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-lib = os.path.join(ROOT, "multimodal_unlearning_amd", "csrc", "variants", "libmmu_hip_attnstamp.so")
+lib = os.environ.get("ATTN_STAMP_LIB") or os.path.join(ROOT, "multimodal_unlearning_amd", "csrc", "variants", "libmmu_hip_attnstamp.so")
 if not os.path.exists(lib):
     subprocess.run([sys.executable, os.path.join(ROOT, "tools", "build_variant.py"), "attnstamp", "-DMMU_ATTN_STAMP"], check=True)
 os.environ["MMU_HIP_LIB"] = lib
@@ -13,7 +13,8 @@ import torch
 from multimodal_unlearning_amd import hip
 L = hip.load()
 L.mmu_debug_read_attn_stamps.argtypes = [C.c_void_p, C.c_int]; L.mmu_debug_read_attn_stamps.restype = C.c_int
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+_pos = [x for x in sys.argv[1:] if not x.startswith("--")]
+B = int(_pos[0]) if _pos else 30
 H, S, D = 32, 1088, 128
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev).manual_seed(0)
@@ -29,6 +30,29 @@ hip.attn_fwd(qkv[:, :HD], qkv[:, HD:2*HD], qkv[:, 2*HD:], o, lse, None, B, S, H,
 for _ in range(3):
     hip.attn_bwd(qkv[:, :HD], qkv[:, HD:2*HD], qkv[:, 2*HD:], o, lse, None, do, delta, dqkv[:, :HD], dqkv[:, HD:2*HD], dqkv[:, 2*HD:], B, S, H, D, sc, True)
 torch.cuda.synchronize()
+if "--dkdv4" in sys.argv:
+    # the four-wave kernel's own stamps (wave 0 of each workgroup): 8 words per workgroup
+    hip.attn_set_dkdv_variant(4)
+    for _ in range(3):
+        hip.attn_bwd(qkv[:, :HD], qkv[:, HD:2*HD], qkv[:, 2*HD:], o, lse, None, do, delta, dqkv[:, :HD], dqkv[:, HD:2*HD], dqkv[:, 2*HD:], B, S, H, D, sc, True)
+    torch.cuda.synchronize()
+    L.mmu_debug_read_dkdv4_stamps.argtypes = [C.c_void_p, C.c_int]; L.mmu_debug_read_dkdv4_stamps.restype = C.c_int
+    # per persistent workgroup: [items, steps, vmcnt waits, barrier waits, total, item epilogues, clean step bodies, their count]
+    n = 256
+    buf = (C.c_ulonglong * (8 * n))()
+    assert L.mmu_debug_read_dkdv4_stamps(buf, n) == 0
+    rows = [tuple(buf[8*i:8*i+8]) for i in range(n)]
+    rows = [r for r in rows if r[0] > 0]
+    med = lambda f: statistics.median(f(x) for x in rows)
+    print(f"workgroups {len(rows)}: items {med(lambda x: x[0]):.0f}, steps {med(lambda x: x[1]):.0f}, total {med(lambda x: x[4]):.0f} ticks "
+          f"(min {min(x[4] for x in rows)}, max {max(x[4] for x in rows)})  [s_memtime ticks, wave 0, medians over workgroups]")
+    print(f"per step: {med(lambda x: x[4]/x[1]):.0f} total | vmcnt wait {med(lambda x: x[2]/x[1]):.0f} | barrier wait {med(lambda x: x[3]/x[1]):.0f} | "
+          f"clean step body {med(lambda x: x[6]/max(1,x[7])):.0f} ({med(lambda x: x[7]/x[1])*100:.0f}% of steps)")
+    print(f"per item: epilogue (scale, RoPE, bf16, next K/V request, stores, wait) {med(lambda x: x[5]/x[0]):.0f}")
+    tot = sum(x[4] for x in rows)
+    sh = lambda k: 100 * sum(x[k] for x in rows) / tot
+    print("shares of workgroup time: vmcnt waits %.1f%%, barrier waits %.1f%%, clean bodies %.1f%%, item epilogues %.1f%%" % (sh(2), sh(3), sh(6), sh(5)))
+    sys.exit(0)
 n = min(16384, 9 * H * B)
 buf = (C.c_ulonglong * (4 * n))()
 assert L.mmu_debug_read_attn_stamps(buf, n) == 0

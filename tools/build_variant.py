@@ -11,7 +11,7 @@ os.makedirs(out, exist_ok=True)
 objs = []
 for s in B.SOURCES:
     o = os.path.join(out, f"{name}_{s.replace('.hip', '.o')}")
-    subprocess.run([B.HIPCC, *B.FLAGS, *flags, "-c", os.path.join(B.CSRC, s), "-o", o], check=True)
+    subprocess.run([B.HIPCC, *B.FLAGS, *B.EXTRA_FLAGS.get(s, []), *flags, "-c", os.path.join(B.CSRC, s), "-o", o], check=True)
     objs.append(o)
 lib = os.path.join(out, f"libmmu_hip_{name}.so")
 subprocess.run([B.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs], check=True)
