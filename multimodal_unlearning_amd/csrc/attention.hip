@@ -710,7 +710,10 @@ int launch_fwd(const AttnArgs& a, hipStream_t s) {
     return 0;
 }
 
-static int g_dkdv_variant = 8;  // mmu_attn_set_dkdv_variant: 8 = eight-wave kernel, 4 = four-wave register-resident kernel
+#ifndef MMU_DKDV_DEFAULT
+#define MMU_DKDV_DEFAULT 4
+#endif
+static int g_dkdv_variant = MMU_DKDV_DEFAULT;  // mmu_attn_set_dkdv_variant: 8 = eight-wave kernel, 4 = four-wave persistent kernel
 
 template <int D, bool CAUSAL>
 int launch_bwd(const AttnArgs& a, hipStream_t s) {
@@ -818,7 +821,8 @@ extern "C" int mmu_debug_read_attn_stamps(unsigned long long* host_out, int n_bl
 #endif
 
 // dK/dV kernel of the head_dim-128 backward: 8 = eight waves, K / V tiles in LDS, two partial sums per key group;
-// 4 = four waves with K / V fragments in registers and a 4-stage Q/dO ring.  Process-wide A/B / tuning switch.
+// 4 (default: -0.6 % step time in a same-box A/B, profiles/r02_dkdv4_instep_ab.txt) = four waves, persistent, K / V
+// fragments in registers and a 4-stage Q/dO ring.  Process-wide A/B / tuning switch.
 // Bits 8 and up: workgroups of the persistent four-wave kernel (0 = one per CU, else a multiple of 8; the tests use a
 // small grid so that every workgroup crosses item seams).
 extern "C" int mmu_attn_set_dkdv_variant(int v) {

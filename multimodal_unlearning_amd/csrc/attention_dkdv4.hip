@@ -23,20 +23,24 @@ __device__ __forceinline__ void glds4_asm(const void* gsrc, unsigned lds_wave_ba
                  : "v"(gsrc), "s"(lds_wave_base)
                  : "memory");
 }
-// Scalar base + 32-bit per-lane byte offset (the steady state: one VGPR per piece, no 64-bit address arithmetic)
+// Scalar base + 32-bit per-lane byte offset (the steady state: one VGPR per piece, no 64-bit address arithmetic).  M0
+// is not saved here: nothing else in this translation unit reads M0 (LDS instructions do not on gfx9+, and there is no
+// compiler-generated LDS-DMA, s_movrel or sendmsg in the kernel — check the .s for `m0` after a compiler change).
 __device__ __forceinline__ void glds16_sv(const void* sbase, unsigned voff, unsigned lds_wave_base) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(sbase), "s"(lds_wave_base)
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_wave_base)
                  : "memory");
 }
-__device__ __forceinline__ void glds4_sv(const void* sbase, unsigned voff, unsigned lds_wave_base) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(sbase), "s"(lds_wave_base)
-                 : "memory");
+// 4 B per lane from scalar base + 4 * lane; the lane offset is formed inside the statement (v_mbcnt ignores EXEC), so no
+// VGPR has to stay live for it across the step loop (hipcc spilled exactly that one to scratch, and its reload
+// brought an `s_waitcnt vmcnt(0)` into every step)
+__device__ __forceinline__ void glds4_lane(const void* sbase, unsigned lds_wave_base) {
+    unsigned t;
+    asm volatile(
+        "v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0\n\tv_lshlrev_b32 %0, 2, %0\n\t"
+        "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1"
+        : "=&v"(t)
+        : "s"(sbase), "s"(lds_wave_base)
+        : "memory");
 }
 
 // s_waitcnt immediates (gfx9 layout: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] at [15:14])
@@ -65,7 +69,7 @@ constexpr int waitcnt_vm(int n) { return (n & 15) | ((n >> 4) << 14) | 0x0F70; }
 // one workgroup per CU meeting at a barrier with the next stage only one iteration ahead.
 // ------------------------------------------------------------------------------------------------
 #ifndef DKDV4_EXP  // timing experiments only (tools/attn_stamps.py): 1 no in-step DMA, 2 no softmax VALU, 4 no transposed
-#define DKDV4_EXP 0  // LDS reads, 8 no stores, 16 no row LDS reads — results are garbage, addresses unchanged
+#define DKDV4_EXP 0  // LDS reads, 8 no stores, 16 no row LDS reads, 32 no K/V reload — results are garbage, addresses unchanged
 #endif
 constexpr int DKDV4_STAGES = 4;
 constexpr int DKDV4_STORES = 16;  // global stores per wave and item (8 x 16 B per lane for dK, 8 for dV)
@@ -77,10 +81,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv4_kernel(AttnArgs a, int 
     constexpr int TB = 64 * D * 2;             // one 64-row tile (Q or dO): 16 KiB
     constexpr int STB = 2 * TB;                // Q | dO of one stage: 32 KiB
     constexpr int ROWC = DKDV4_STAGES * STB;   // row constants: [stage][lse2 64 | delta 64] floats
+    constexpr int XLDS = ROWC + DKDV4_STAGES * 512;  // 4 x 4 KiB: each wave's transposition area for its stores
     constexpr int NKS = D / 16, NDT = D / 32, NST = DKDV4_STAGES;
     STAMP(t_start);
 #ifdef MMU_ATTN_STAMP
-    unsigned long long t_vm = 0, t_bar = 0, t_clean = 0, n_clean = 0, t_epi = 0, n_it = 0, n_steps = 0;
+    unsigned long long t_vm = 0, t_bar = 0, t_clean = 0, n_clean = 0, t_epi = 0, n_it = 0, n_steps = 0, t_e_math = 0, t_e_kv = 0,
+                       t_e_st = 0, t_masked = 0;
 #endif
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -121,6 +127,22 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv4_kernel(AttnArgs a, int 
     const bf16* d_do;
     const float* d_lse;
     const float* d_dl;
+    // per stage (dma_stage): this wave's first piece of the Q / dO tile, its 32 row constants, its LDS addresses
+    const char* s_q;
+    const char* s_do;
+    const float* s_rc;
+    unsigned s_lds, s_lds_rc;
+    bool s_full;
+    const size_t pstride_q = (size_t)a.ld * 8, pstride_do = (size_t)a.lddo * 8;  // 4 rows, bytes
+    auto dma_stage = [&]() {
+        const int row0 = d_pr * 64;
+        s_full = row0 + 64 <= S;
+        s_q = reinterpret_cast<const char*>(d_q + (size_t)(row0 + wave * 16) * a.ld);
+        s_do = reinterpret_cast<const char*>(d_do + (size_t)(row0 + wave * 16) * a.lddo);
+        s_rc = (wave < 2 ? d_lse : d_dl) + row0 + (wave & 1) * 32;
+        s_lds = lds_base + (issued % NST) * STB + wave * 4096;
+        s_lds_rc = lds_base + ROWC + ((issued % NST) * 128 + (wave >> 1) * 64 + (wave & 1) * 32) * 4;
+    };
     auto dma_open = [&](int v) {
         int kvb, hh, b;
         decode_wg_at(v, nx, a.H, a.B, false, kvb, hh, b);
@@ -133,45 +155,43 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv4_kernel(AttnArgs a, int 
         d_pr1 = (S + 63) / 64;
     };
     dma_open(d_item);
-    // piece p (0..3 Q, 4..7 dO, 8 row constants) of the cursor's stage
-    auto dma_piece = [&](int p) {
-        const unsigned slot = lds_base + (issued % NST) * STB;
+    dma_stage();
+    // a ragged stage (the last rows of a sequence that is not a multiple of 64): all nine pieces at once, per-lane
+    // addresses; rows past the sequence re-read row S-1 (their lse2 is +inf: P = 0 exactly)
+    auto dma_ragged_stage = [&]() {
         const int row0 = d_pr * 64;
-        const bool full = row0 + 64 <= S;
-        if (p < 8) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
             const int t = p & 3;
             const bool is_do = p >= 4;
             const int ld = is_do ? a.lddo : a.ld;
-            const int prow = (wave * 4 + t) * 4;  // first row of the piece inside the tile
-            const unsigned dst = slot + (is_do ? TB : 0) + (wave * 4 + t) * 1024;
-            const bf16* base;
-            unsigned off;
-            if (full) {
-                base = (is_do ? d_do : d_q) + (size_t)(row0 + prow) * ld;
-                off = (is_do ? do_off0 : q_off0) ^ (unsigned)(t << 4);
-            } else {  // rows past the sequence re-read row S-1 (their lse2 is +inf: P = 0 exactly)
-                base = (is_do ? d_do : d_q) + (size_t)row0 * ld;
-                const int row = min(prow + (lane >> 4), S - 1 - row0);
-                off = (unsigned)(row * ld) * 2u + (unsigned)((((lane & 15) ^ ((lane >> 4) << 2)) ^ t) << 4);
-            }
-            glds16_sv(base, off, __builtin_amdgcn_readfirstlane(dst));
-        } else if (lane < 32) {  // waves 0,1: lse2 rows [0,32) / [32,64); waves 2,3: delta rows likewise
-            const int qr = row0 + (wave & 1) * 32 + lane;
-            const unsigned dst = lds_base + ROWC + ((issued % NST) * 128 + (wave >> 1) * 64 + (wave & 1) * 32) * 4;
-            if (full) {
-                glds4_sv((wave < 2 ? d_lse : d_dl) + row0 + (wave & 1) * 32, (unsigned)lane * 4u,
-                         __builtin_amdgcn_readfirstlane(dst));
-            } else {
-                const float* src = wave < 2 ? (qr < S ? d_lse + qr : reinterpret_cast<const float*>(mmu_inf16))
-                                            : (qr < S ? d_dl + qr : reinterpret_cast<const float*>(mmu_zero16));
-                glds4_asm(src, __builtin_amdgcn_readfirstlane(dst));
-            }
+            const int row = min(row0 + (wave * 4 + t) * 4 + (lane >> 4), S - 1);
+            const bf16* src = (is_do ? d_do : d_q) + (size_t)row * ld + ((((lane & 15) ^ ((lane >> 4) << 2)) ^ t) << 3);
+            glds16_asm(src, __builtin_amdgcn_readfirstlane(s_lds + (is_do ? TB : 0) + t * 1024));
         }
+        if (lane < 32) {
+            const int qr = row0 + (wave & 1) * 32 + lane;
+            const float* src = wave < 2 ? (qr < S ? d_lse + qr : reinterpret_cast<const float*>(mmu_inf16))
+                                        : (qr < S ? d_dl + qr : reinterpret_cast<const float*>(mmu_zero16));
+            glds4_asm(src, __builtin_amdgcn_readfirstlane(s_lds_rc));
+        }
+    };
+    // piece p (0..3 Q, 4..7 dO, 8 row constants: waves 0,1 lse2 rows [0,32) / [32,64), waves 2,3 delta likewise) of the
+    // cursor's stage
+    auto dma_piece = [&](int p) {
+        if (!s_full) {
+            if (p == 0) dma_ragged_stage();
+            return;
+        }
+        if (p < 4) glds16_sv(s_q + p * pstride_q, q_off0 ^ (unsigned)(p << 4), s_lds + p * 1024);
+        else if (p < 8) glds16_sv(s_do + (p - 4) * pstride_do, do_off0 ^ (unsigned)((p - 4) << 4), s_lds + TB + (p - 4) * 1024);
+        else if (lane < 32) glds4_lane(s_rc, s_lds_rc);
     };
     auto dma_advance = [&]() {
         ++issued;
         if (d_pr + 1 < d_pr1) ++d_pr;
         else if (d_item + G < n_items) { d_item += G; dma_open(d_item); }
+        dma_stage();
     };
     bool in_steps = false;
     auto dma_pieces = [&](int p0, int n) {
@@ -215,7 +235,6 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv4_kernel(AttnArgs a, int 
         const int key0 = kvb * 128 + wave * 32;
         const int key = key0 + (lane & 31);
         const bool all_valid = __all(kvalid);
-        const size_t rowbase = (size_t)b * S;
 #pragma unroll
         for (int i = 0; i < NDT; ++i)
 #pragma unroll
@@ -257,9 +276,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv4_kernel(AttnArgs a, int 
             };
             // One 32-row query tile against this wave's 32 keys, four scheduling regions of 8 MFMAs each; every region
             // carries the LDS reads of a LATER region and the VALU work of an EARLIER one between its MFMAs:
-            //   R1  S = Q K^T chain          | transposed dO^T, Q^T fragments of rows 0..15, dO row fragments
-            //   R2  dP = dO V^T chain        | P = exp2(S c - lse2), its bf16 fragments | transposed fragments, rows 16..31, delta
-            //   R3  dV^T += dO^T P           | dS = P (dP - delta) and its bf16 fragments
+            //   R1  S = Q K^T chain          | transposed dO^T fragments of rows 0..15, dO row fragments
+            //   R2  dP = dO V^T chain        | P = exp2(S c - lse2), its bf16 fragments | transposed dO^T, rows 16..31, delta
+            //   R3  dV^T += dO^T P           | dS = P (dP - delta) and its bf16 fragments | transposed Q^T fragments
             //   R4  dK^T += Q^T dS           | Q row fragments + lse2 of the NEXT tile (next >= 0)
             // DMA pieces p0 .. p0+np-1 of the stage three steps ahead go out at the region boundaries.
             // MASKED: causal diagonal / padded keys: rows below `kd2 + 4 hl` (per lane) get P = 0.
@@ -284,16 +303,15 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv4_kernel(AttnArgs a, int 
                 for (int ks = 0; ks < NKS; ++ks) sv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[ks], kf[ks], sv, 0, 0, 0);
 #pragma unroll
                 for (int dt = 0; dt < NDT; ++dt) {
-                    if (DKDV4_EXP & 4) { to[dt] = kf[dt]; tq[dt] = vf[dt]; continue; }
+                    if (DKDV4_EXP & 4) { to[dt] = kf[dt]; continue; }
                     to[dt] = tr_load(qtile + TB + off_tr1[dt], qtile + TB + off_tr2[dt]);
-                    tq[dt] = tr_load(qtile + off_tr1[dt], qtile + off_tr2[dt]);
                 }
 #pragma unroll
                 for (int ks = 0; ks < NKS; ++ks)
                     if (!(DKDV4_EXP & 16)) fo[ks] = *(const MMU_LDS bf16x8*)(qtile + TB + off_row[ks]);
                     else fo[ks] = kf[ks];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) { SG(0x8, 1); SG(0x100, 3); }
+                for (int i = 0; i < 8; ++i) { SG(0x8, 1); SG(0x100, 2); }
                 SB();
                 dma_pieces(p0 + n1, n2);
                 // ---- R2
@@ -312,16 +330,15 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv4_kernel(AttnArgs a, int 
                 const bf16x8 pf = pack8(sv, 0), pf2 = pack8(sv, 1);
 #pragma unroll
                 for (int dt = 0; dt < NDT; ++dt) {
-                    if (DKDV4_EXP & 4) { to2[dt] = kf[4 + dt]; tq2[dt] = vf[4 + dt]; continue; }
+                    if (DKDV4_EXP & 4) { to2[dt] = kf[4 + dt]; continue; }
                     to2[dt] = tr_load(qtile + 16 * (D * 2) + TB + off_tr1[dt], qtile + 16 * (D * 2) + TB + off_tr2[dt]);
-                    tq2[dt] = tr_load(qtile + 16 * (D * 2) + off_tr1[dt], qtile + 16 * (D * 2) + off_tr2[dt]);
                 }
 #pragma unroll
                 for (int g = 0; g < 4; ++g) d[g] = *(const MMU_LDS f32x4*)(rc + 64 + half * 32 + 8 * g + 4 * hl);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { SG(0x8, 1); SG(0x100, 3); SG(0x2, MASKED ? 10 : 7); }
-#pragma unroll
                 for (int i = 0; i < 4; ++i) { SG(0x8, 1); SG(0x100, 2); SG(0x2, MASKED ? 10 : 7); }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { SG(0x8, 1); SG(0x100, 1); SG(0x2, MASKED ? 10 : 7); }
                 SB();
                 dma_pieces(p0 + n1 + n2, n3);
                 // ---- R3
@@ -330,13 +347,19 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv4_kernel(AttnArgs a, int 
 #pragma unroll
                 for (int dt = 0; dt < NDT; ++dt) dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(to2[dt], pf2, dv[dt], 0, 0, 0);
 #pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) {
+                    if (DKDV4_EXP & 4) { tq[dt] = vf[dt]; tq2[dt] = vf[4 + dt]; continue; }
+                    tq[dt] = tr_load(qtile + off_tr1[dt], qtile + off_tr2[dt]);
+                    tq2[dt] = tr_load(qtile + 16 * (D * 2) + off_tr1[dt], qtile + 16 * (D * 2) + off_tr2[dt]);
+                }
+#pragma unroll
                 for (int g = 0; g < 4; ++g)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         if (!(DKDV4_EXP & 2)) dpv[4 * g + j] = sv[4 * g + j] * (dpv[4 * g + j] - d[g][j]);
                 const bf16x8 dsf = pack8(dpv, 0), dsf2 = pack8(dpv, 1);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) { SG(0x8, 1); SG(0x2, 5); }
+                for (int i = 0; i < 8; ++i) { SG(0x8, 1); SG(0x100, 2); SG(0x2, 5); }
                 SB();
                 dma_pieces(p0 + n1 + n2 + n3, n4);
                 // ---- R4
@@ -366,6 +389,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv4_kernel(AttnArgs a, int 
                 n_clean += 1;
 #endif
             } else {
+                STAMP(t_m0);
                 dma_pieces(0, 9);
                 for (int half = 0; half < 2; ++half) {
                     if (!(half ? act1 : act0)) continue;
@@ -373,19 +397,18 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv4_kernel(AttnArgs a, int 
                     SB();
                     tile(std::true_type{}, half, -1, 0, 0, fq, l4);
                 }
+#ifdef MMU_ATTN_STAMP
+                t_masked += stamp_now() - t_m0;
+#endif
             }
 #undef SB
 #undef SG
         }
 
         // ---- the item's gradients: scale dK, transpose rotation of RoPE on the (d, d+64) pairs of dK (same arithmetic
-        // as rope_kernel(inverse=1) on the bf16-rounded gradient), bf16, and 16-B stores: lane (key, hl) holds
-        // d = 32 dt + 8 g + 4 hl + j; one v_permlane32_swap per dword trades the odd-g words of the hl = 0 lanes for the
-        // even-g words of the hl = 1 lanes, so every lane ends up with 8 consecutive d of its key.
+        // as rope_kernel(inverse=1) on the bf16-rounded gradient), bf16; lane (key, hl) holds d = 32 dt + 8 g + 4 hl + j.
         STAMP(t_e0);
-        const int out_key = key;
-        const size_t out_row = rowbase + key;
-        const int out_hh = hh;
+        const int out_key = key, out_hh = hh, out_b = b;  // the row index is re-formed below (a 64-bit VGPR pair less to keep)
         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
         u32x2 wk[NDT][4], wv[NDT][4];  // bf16x4 words of dK / dV per (dt, g)
@@ -395,7 +418,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv4_kernel(AttnArgs a, int 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) dk[dt][r] *= a.scale;
             if (a.rope_pos) {
-                const int pos = out_key < S ? a.rope_pos[out_row] : 0;
+                const int pos = out_key < S ? a.rope_pos[(size_t)out_b * S + out_key] : 0;
                 const bf16* cr = a.rope_cos + (size_t)pos * 64;
                 const bf16* sr = a.rope_sin + (size_t)pos * 64;
 #pragma unroll
@@ -437,41 +460,57 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv4_kernel(AttnArgs a, int 
                     wv[dt][g] = __builtin_bit_cast(u32x2, t);
                 }
         }
+        STAMP(t_e1);
         // the next item's K / V (and key mask) are requested BEFORE this item's stores go out; the wait in front of the
         // next item's first step then only has to leave the stores outstanding
         const bool more = item + G < n_items;
         if (more) {
             decode_wg_at(item + G, nx, a.H, a.B, false, kvb, hh, b);
-            load_kv(kvb, hh, b);
+            if (!((DKDV4_EXP & 32) && a.scale != 12345.f)) load_kv(kvb, hh, b);
         }
+        STAMP(t_e2);
+        // Stores: a wave instruction that writes "one key per lane" touches 32 rows (32 B each) and costs ~440 cycles of
+        // issue (measured: 7.1 k cycles for the 16 of an item); instead each half matrix (32 keys x 64 d) goes through a
+        // 4-KiB LDS area private to the wave — 8 ds_write_b64 in, 4 ds_read_b128 out with 8 lanes per key — so a store
+        // instruction writes 8 whole 128-B lines.  [key][16 granules of 8 B], granule ^= ((key >> 1) & 3) << 1.
         const bool stores = key0 < S;  // wave-uniform
-        if (out_key < S && !(DKDV4_EXP & 8)) {
-            bf16* dkp = a.dk + out_row * a.ldg + out_hh * D;
-            bf16* dvp = a.dv + out_row * a.ldg + out_hh * D;
+        if (stores && !((DKDV4_EXP & 8) && a.scale != 12345.f)) {  // (the experiment keeps the stores reachable: no DCE)
+            MMU_LDS char* xw = (MMU_LDS char*)smem + XLDS + wave * 4096;
+            int lane_e = lane;
+            asm volatile("" : "+v"(lane_e));  // keeps the address arithmetic below here (hoisted to the item's top it was spilled)
+            const int kr = lane_e & 31, rr = lane_e >> 3, hl_e = lane_e >> 5;
+            const int w0 = kr * 128 + ((hl_e ^ (((kr >> 1) & 3) << 1)) << 3);
+            const int r0 = rr * 128 + (((lane_e & 7) ^ ((rr >> 1) & 3)) << 4);
+            const size_t out_off = ((size_t)out_b * S + key0 + rr) * a.ldg + out_hh * D + (lane_e & 7) * 8;
 #pragma unroll
-            for (int dt = 0; dt < NDT; ++dt)
+            for (int mat = 0; mat < 2; ++mat) {
+                bf16* gp = (mat ? a.dv : a.dk) + out_off;
 #pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    u32x4 ok, ov;
+                for (int h = 0; h < 2; ++h) {
 #pragma unroll
-                    for (int w = 0; w < 2; ++w) {
-                        // x = words of g = 2m (kept by hl = 0), y = words of g = 2m+1 (kept by hl = 1)
-                        auto sk = __builtin_amdgcn_permlane32_swap(wk[dt][2 * m][w], wk[dt][2 * m + 1][w], false, false);
-                        auto sv2 = __builtin_amdgcn_permlane32_swap(wv[dt][2 * m][w], wv[dt][2 * m + 1][w], false, false);
-                        ok[w] = sk[0]; ok[2 + w] = sk[1];
-                        ov[w] = sv2[0]; ov[2 + w] = sv2[1];
-                    }
-                    const int d = dt * 32 + 16 * m + 8 * hl;
-                    *reinterpret_cast<u32x4*>(dkp + d) = ok;
-                    *reinterpret_cast<u32x4*>(dvp + d) = ov;
+                    for (int dtl = 0; dtl < 2; ++dtl)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            *(MMU_LDS u32x2*)(xw + (w0 ^ (g << 4)) + dtl * 64) = mat ? wv[2 * h + dtl][g] : wk[2 * h + dtl][g];
+                    u32x4 rows[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) rows[i] = *(const MMU_LDS u32x4*)(xw + r0 + i * 1024);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (key0 + i * 8 + rr < S) *reinterpret_cast<u32x4*>(gp + (size_t)i * 8 * a.ldg + h * 64) = rows[i];
                 }
+            }
         }
+        STAMP(t_e3);
         if (more) {
             if (stores) __builtin_amdgcn_s_waitcnt(waitcnt_vm(DKDV4_STORES));
             else __builtin_amdgcn_s_waitcnt(waitcnt_vm(0));
         }
 #ifdef MMU_ATTN_STAMP
         t_epi += stamp_now() - t_e0;
+        t_e_math += t_e1 - t_e0;
+        t_e_kv += t_e2 - t_e1;
+        t_e_st += t_e3 - t_e2;
         n_it += 1;
 #endif
     }
@@ -479,10 +518,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv4_kernel(AttnArgs a, int 
 #ifdef MMU_ATTN_STAMP
     {
         const unsigned long long t_end = stamp_now();
-        if (threadIdx.x == 0 && blockIdx.x < 8192) {
-            unsigned long long* o = g_attn_stamps + 8 * blockIdx.x;
+        if (threadIdx.x == 0 && blockIdx.x < 4096) {
+            unsigned long long* o = g_attn_stamps + 16 * blockIdx.x;
             o[0] = n_it; o[1] = n_steps; o[2] = t_vm; o[3] = t_bar;
             o[4] = t_end - t_start; o[5] = t_epi; o[6] = t_clean; o[7] = n_clean;
+            o[8] = t_e_math; o[9] = t_e_kv; o[10] = t_e_st; o[11] = t_masked;
         }
     }
 #endif
@@ -495,7 +535,7 @@ int g_dkdv4_grid = 0;  // 0 = one workgroup per CU
 #ifdef MMU_ATTN_STAMP
 extern "C" int mmu_debug_read_dkdv4_stamps(unsigned long long* host_out, int n_blocks) {
     if (hipDeviceSynchronize() != hipSuccess) return 1;
-    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_attn_stamps), (size_t)n_blocks * 64, 0, hipMemcpyDeviceToHost);
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_attn_stamps), (size_t)n_blocks * 128, 0, hipMemcpyDeviceToHost);
 }
 #endif
 
@@ -507,7 +547,7 @@ int mmu_internal_set_dkdv4_grid(int n) {
 
 int mmu_internal_launch_dkdv4(const void* attn_args, int causal, hipStream_t stream) {
     const AttnArgs& a = *reinterpret_cast<const AttnArgs*>(attn_args);
-    constexpr int LDS4 = DKDV4_STAGES * (2 * 64 * 128 * 2) + DKDV4_STAGES * 128 * 4;
+    constexpr int LDS4 = DKDV4_STAGES * (2 * 64 * 128 * 2) + DKDV4_STAGES * 128 * 4 + 4 * 4096;
     static bool cfg[2] = {false, false};
     static int n_cu = 0;
     if (!cfg[causal ? 1 : 0]) {

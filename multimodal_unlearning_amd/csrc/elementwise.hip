@@ -663,6 +663,11 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16* __restrict__
     __shared__ __attribute__((aligned(16))) unsigned int tileT[64][NP + 4];    // [source column][row pair]
     const int r0 = blockIdx.y * TR, c0 = blockIdx.x * 64;
     const int tc = (threadIdx.x & 7) * 8;
+    // The 8 threads of a row pair write columns 8 apart: with a row stride of NP + 4 dwords that is the same bank for all
+    // of them (8 x (NP + 4) = 0 mod 32: 8-way conflicts on every ds_write_b32, which bounded these kernels at ~2.5 TB/s).
+    // XOR-ing the 4-dword chunk index of the row pair with (column >> 3) & 7 spreads them over all 32 banks; the read
+    // side takes whole chunks, so it only XORs its chunk index the same way.
+    const int sw = (threadIdx.x & 7) << 2;
 #pragma unroll
     for (int g = 0; g < NP / 32; ++g) {
         const int tp = (threadIdx.x >> 3) + g * 32;  // row pair
@@ -678,8 +683,8 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16* __restrict__
         const unsigned int aw[4] = {au.x, au.y, au.z, au.w}, bw[4] = {bu.x, bu.y, bu.z, bu.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {  // dword k holds columns 2k (low half) and 2k+1 (high half)
-            tileT[tc + 2 * k][tp] = (aw[k] & 0xffffu) | (bw[k] << 16);
-            tileT[tc + 2 * k + 1][tp] = (aw[k] >> 16) | (bw[k] & 0xffff0000u);
+            tileT[tc + 2 * k][tp ^ sw] = (aw[k] & 0xffffu) | (bw[k] << 16);
+            tileT[tc + 2 * k + 1][tp ^ sw] = (aw[k] >> 16) | (bw[k] & 0xffff0000u);
         }
     }
     __syncthreads();
@@ -691,7 +696,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16* __restrict__
         const int q = threadIdx.x % QPR;             // 8 source rows = 4 row pairs = 16 B
         const int c = c0 + cl, r = r0 + q * 8;
         if (c < C && r < R) {
-            const uint4 v = *reinterpret_cast<const uint4*>(&tileT[cl][q * 4]);
+            const uint4 v = *reinterpret_cast<const uint4*>(&tileT[cl][(q ^ ((cl >> 3) & 7)) * 4]);
             *reinterpret_cast<uint4*>(dst + (size_t)c * R + r) = v;
         }
     }
@@ -699,7 +704,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16* __restrict__
 
 
 // ------------------------------------------------------------------------------------------------
-// Fused "elementwise producer -> transposed output" kernels: a 64x64 tile is computed in registers, staged in
+// Fused "elementwise producer -> transposed output" kernels: a 64-column tile is computed in registers, staged in
 // LDS and written transposed ([cols][rows], 16-B stores), so the wgrad operands X^T / dY^T come out of their
 // producers directly instead of a separate transpose pass (saves a full write + read of the tensor).
 // MODE 0: act^T  = (bf16(silu(g)) * u)^T              from gate|up [M][2I]            (SwiGLU recompute in backward)
@@ -708,69 +713,98 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16* __restrict__
 // MODE 3: act and act^T from gate|up                  (SwiGLU forward that also leaves the down-proj wgrad operand)
 // R rows (tokens), C columns of the OUTPUT of the elementwise op; R % 8 == 0, C % 8 == 0.
 // ------------------------------------------------------------------------------------------------
-template <int MODE>
+// Tile: 64 columns x TR source rows staged exactly like transpose_kernel (a thread computes 8 columns of two adjacent
+// rows, packs each column's row pair into one dword, [column][row pair] image, one 16-B LDS read per 16-B store), so the
+// transposed output leaves in runs of TR * 2 bytes per output row and workgroup — the 64 x 64 version of this kernel
+// wrote 128-B runs and ran at 2.1-2.5 TB/s in the step (profiles/r02_rocprofv3_kernel_stats.csv).
+#ifndef MMU_FUSED_T_ROWS
+#define MMU_FUSED_T_ROWS 128
+#endif
+template <int MODE, int TR>
 __global__ __launch_bounds__(256) void fused_t_kernel(const bf16* __restrict__ in0, const bf16* __restrict__ in1,
                                                       const float* __restrict__ rstd, bf16* __restrict__ out_n,
                                                       bf16* __restrict__ out_t, int R, int C) {
-    __shared__ bf16 tile[(MODE == 2 ? 2 : 1)][64][72];
-    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
-    const int tr = threadIdx.x >> 3, tc = (threadIdx.x & 7) * 8;
+    constexpr int NP = TR / 2;            // row pairs per tile
+    constexpr int NT = MODE == 2 ? 2 : 1;  // transposed outputs
+    __shared__ __attribute__((aligned(16))) unsigned int tileT[NT][64][NP + 4];  // [output][source column][row pair]
+    const int r0 = blockIdx.y * TR, c0 = blockIdx.x * 64;
+    const int tc = (threadIdx.x & 7) * 8;
+    const int c = c0 + tc;
+    const int sw = (threadIdx.x & 7) << 2;  // bank swizzle of the staged image, see transpose_kernel
+    bf16x8 w8;
+    if (MODE == 1 && c < C) w8 = *reinterpret_cast<const bf16x8*>(in1 + c);
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const int r = r0 + tr + p * 32, c = c0 + tc;
-        bf16x8 o0, o1;
+    for (int g = 0; g < NP / 32; ++g) {
+        const int tp = (threadIdx.x >> 3) + g * 32;  // row pair
+        bf16x8 o0[2], o1[2];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { o0[j] = f2bf(0.f); o1[j] = f2bf(0.f); }
-        if (r < R && c < C) {
-            if (MODE == 0 || MODE == 3) {
-                const bf16x8 g = *reinterpret_cast<const bf16x8*>(in0 + (size_t)r * 2 * C + c);
-                const bf16x8 u = *reinterpret_cast<const bf16x8*>(in0 + (size_t)r * 2 * C + C + c);
+        for (int h = 0; h < 2; ++h) {
+            const int r = r0 + 2 * tp + h;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float gf = bf2f(g[j]);
-                    o0[j] = f2bf(round_bf16(gf / (1.0f + __expf(-gf))) * bf2f(u[j]));
+            for (int j = 0; j < 8; ++j) { o0[h][j] = f2bf(0.f); o1[h][j] = f2bf(0.f); }
+            if (r < R && c < C) {
+                if (MODE == 0 || MODE == 3) {
+                    const bf16x8 gg = *reinterpret_cast<const bf16x8*>(in0 + (size_t)r * 2 * C + c);
+                    const bf16x8 u = *reinterpret_cast<const bf16x8*>(in0 + (size_t)r * 2 * C + C + c);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float gf = bf2f(gg[j]);
+                        o0[h][j] = f2bf(round_bf16(gf / (1.0f + __expf(-gf))) * bf2f(u[j]));
+                    }
+                    if (MODE == 3) *reinterpret_cast<bf16x8*>(out_n + (size_t)r * C + c) = o0[h];
+                } else if (MODE == 1) {
+                    const bf16x8 x = *reinterpret_cast<const bf16x8*>(in0 + (size_t)r * C + c);
+                    const float rs = rstd[r];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o0[h][j] = f2bf(bf2f(w8[j]) * round_bf16(bf2f(x[j]) * rs));
+                } else {
+                    const bf16x8 gg = *reinterpret_cast<const bf16x8*>(in0 + (size_t)r * 2 * C + c);
+                    const bf16x8 u = *reinterpret_cast<const bf16x8*>(in0 + (size_t)r * 2 * C + C + c);
+                    const bf16x8 d = *reinterpret_cast<const bf16x8*>(in1 + (size_t)r * C + c);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float gf = bf2f(gg[j]), uf = bf2f(u[j]), df = bf2f(d[j]);
+                        const float sig = 1.0f / (1.0f + __expf(-gf));
+                        o1[h][j] = f2bf(df * round_bf16(gf * sig));                      // d up
+                        o0[h][j] = f2bf(df * uf * (sig * (1.0f + gf * (1.0f - sig))));   // d gate
+                    }
+                    *reinterpret_cast<bf16x8*>(out_n + (size_t)r * 2 * C + c) = o0[h];
+                    *reinterpret_cast<bf16x8*>(out_n + (size_t)r * 2 * C + C + c) = o1[h];
                 }
-                if (MODE == 3) *reinterpret_cast<bf16x8*>(out_n + (size_t)r * C + c) = o0;
-            } else if (MODE == 1) {
-                const bf16x8 x = *reinterpret_cast<const bf16x8*>(in0 + (size_t)r * C + c);
-                const bf16x8 w = *reinterpret_cast<const bf16x8*>(in1 + c);
-                const float rs = rstd[r];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) o0[j] = f2bf(bf2f(w[j]) * round_bf16(bf2f(x[j]) * rs));
-            } else {
-                const bf16x8 g = *reinterpret_cast<const bf16x8*>(in0 + (size_t)r * 2 * C + c);
-                const bf16x8 u = *reinterpret_cast<const bf16x8*>(in0 + (size_t)r * 2 * C + C + c);
-                const bf16x8 d = *reinterpret_cast<const bf16x8*>(in1 + (size_t)r * C + c);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float gf = bf2f(g[j]), uf = bf2f(u[j]), df = bf2f(d[j]);
-                    const float sig = 1.0f / (1.0f + __expf(-gf));
-                    o1[j] = f2bf(df * round_bf16(gf * sig));                      // d up
-                    o0[j] = f2bf(df * uf * (sig * (1.0f + gf * (1.0f - sig))));   // d gate
-                }
-                *reinterpret_cast<bf16x8*>(out_n + (size_t)r * 2 * C + c) = o0;
-                *reinterpret_cast<bf16x8*>(out_n + (size_t)r * 2 * C + C + c) = o1;
             }
         }
-        *reinterpret_cast<bf16x8*>(&tile[0][tr + p * 32][tc]) = o0;
-        if (MODE == 2) *reinterpret_cast<bf16x8*>(&tile[MODE == 2 ? 1 : 0][tr + p * 32][tc]) = o1;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const uint4 au = __builtin_bit_cast(uint4, t ? o1[0] : o0[0]), bu = __builtin_bit_cast(uint4, t ? o1[1] : o0[1]);
+            const unsigned int aw[4] = {au.x, au.y, au.z, au.w}, bw[4] = {bu.x, bu.y, bu.z, bu.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {  // dword k holds columns 2k (low half) and 2k+1 (high half)
+                tileT[t][tc + 2 * k][tp ^ sw] = (aw[k] & 0xffffu) | (bw[k] << 16);
+                tileT[t][tc + 2 * k + 1][tp ^ sw] = (aw[k] >> 16) | (bw[k] & 0xffff0000u);
+            }
+        }
     }
     __syncthreads();
+    constexpr int QPR = TR / 8;     // 16-B chunks per output row
+    constexpr int RPP = 256 / QPR;  // output rows per pass
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const int c = c0 + tr + p * 32, r = r0 + tc;  // output row = source column
-        if (c < C && r < R) {
-            bf16x8 v;
+    for (int p = 0; p < 64 / RPP; ++p) {
+        const int cl = threadIdx.x / QPR + p * RPP;  // output row = source column
+        const int q = threadIdx.x % QPR;             // 8 source rows = 4 row pairs = 16 B
+        const int cc = c0 + cl, r = r0 + q * 8;
+        if (cc < C && r < R) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = tile[0][tc + j][tr + p * 32];
-            *reinterpret_cast<bf16x8*>(out_t + (size_t)c * R + r) = v;
-            if (MODE == 2) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = tile[MODE == 2 ? 1 : 0][tc + j][tr + p * 32];
-                *reinterpret_cast<bf16x8*>(out_t + (size_t)(C + c) * R + r) = v;
-            }
+            for (int t = 0; t < NT; ++t)
+                *reinterpret_cast<uint4*>(out_t + (size_t)(t * C + cc) * R + r) =
+                    *reinterpret_cast<const uint4*>(&tileT[t][cl][(q ^ ((cl >> 3) & 7)) * 4]);
         }
     }
+}
+template <int MODE>
+void launch_fused_t(const void* in0, const void* in1, const float* rstd, void* out_n, void* out_t, int R, int C, hipStream_t s) {
+    constexpr int TR = (MODE == 2 && MMU_FUSED_T_ROWS > 128) ? 128 : MMU_FUSED_T_ROWS;  // two images: 64 KiB of static LDS at most
+    hipLaunchKernelGGL((fused_t_kernel<MODE, TR>), dim3((C + 63) / 64, (R + TR - 1) / TR), dim3(256), 0, s, (const bf16*)in0,
+                       (const bf16*)in1, rstd, (bf16*)out_n, (bf16*)out_t, R, C);
 }
 
 inline int grid_for(size_t work_items, int block) {
@@ -1044,32 +1078,28 @@ extern "C" int mmu_transpose_bf16(const void* src, void* dst, int R, int C, void
 // act^T [I][M] = swiglu(gate|up [M][2I])^T
 extern "C" int mmu_swiglu_fwd_t(const void* gu, void* actT, int M, int I, void* stream) {
     if (M <= 0 || (I & 7) || (M & 7)) return -1;
-    hipLaunchKernelGGL(fused_t_kernel<0>, dim3((I + 63) / 64, (M + 63) / 64), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16*)gu, (const bf16*)nullptr, (const float*)nullptr, (bf16*)nullptr, (bf16*)actT, M, I);
+    launch_fused_t<0>(gu, nullptr, nullptr, nullptr, actT, M, I, (hipStream_t)stream);
     MMU_CHECK_LAUNCH();
     return 0;
 }
 // act [M][I] and act^T [I][M] in one pass over gate|up (forward; act^T is kept for the down-proj wgrad)
 extern "C" int mmu_swiglu_fwd_both(const void* gu, void* act, void* actT, int M, int I, void* stream) {
     if (M <= 0 || (I & 7) || (M & 7)) return -1;
-    hipLaunchKernelGGL(fused_t_kernel<3>, dim3((I + 63) / 64, (M + 63) / 64), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16*)gu, (const bf16*)nullptr, (const float*)nullptr, (bf16*)act, (bf16*)actT, M, I);
+    launch_fused_t<3>(gu, nullptr, nullptr, act, actT, M, I, (hipStream_t)stream);
     MMU_CHECK_LAUNCH();
     return 0;
 }
 // y^T [d][M] = (w * bf16(x * rstd))^T  (RMSNorm output recomputed from the saved rstd)
 extern "C" int mmu_rmsnorm_apply_t(const void* x, const void* w, const float* rstd, void* yT, int M, int d, void* stream) {
     if (M <= 0 || (d & 7) || (M & 7)) return -1;
-    hipLaunchKernelGGL(fused_t_kernel<1>, dim3((d + 63) / 64, (M + 63) / 64), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16*)x, (const bf16*)w, rstd, (bf16*)nullptr, (bf16*)yT, M, d);
+    launch_fused_t<1>(x, w, rstd, nullptr, yT, M, d, (hipStream_t)stream);
     MMU_CHECK_LAUNCH();
     return 0;
 }
 // dgu [M][2I] and dgu^T [2I][M] from gate|up and dh
 extern "C" int mmu_swiglu_bwd_t(const void* gu, const void* dh, void* dgu, void* dguT, int M, int I, void* stream) {
     if (M <= 0 || (I & 7) || (M & 7)) return -1;
-    hipLaunchKernelGGL(fused_t_kernel<2>, dim3((I + 63) / 64, (M + 63) / 64), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16*)gu, (const bf16*)dh, (const float*)nullptr, (bf16*)dgu, (bf16*)dguT, M, I);
+    launch_fused_t<2>(gu, dh, nullptr, dgu, dguT, M, I, (hipStream_t)stream);
     MMU_CHECK_LAUNCH();
     return 0;
 }

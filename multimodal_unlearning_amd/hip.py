@@ -260,7 +260,7 @@ def attn_bwd(q, k, v, o, lse, kmask, dout, delta, dq, dk, dv, B, S, H, head_dim,
     _check(rc, "mmu_attn_bwd_rope")
 
 
-DKDV_DEFAULT = 8
+DKDV_DEFAULT = 4
 
 
 def attn_set_dkdv_variant(v: int, grid: int = 0):

@@ -39,16 +39,18 @@ if "--dkdv4" in sys.argv:
     L.mmu_debug_read_dkdv4_stamps.argtypes = [C.c_void_p, C.c_int]; L.mmu_debug_read_dkdv4_stamps.restype = C.c_int
     # per persistent workgroup: [items, steps, vmcnt waits, barrier waits, total, item epilogues, clean step bodies, their count]
     n = 256
-    buf = (C.c_ulonglong * (8 * n))()
+    buf = (C.c_ulonglong * (16 * n))()
     assert L.mmu_debug_read_dkdv4_stamps(buf, n) == 0
-    rows = [tuple(buf[8*i:8*i+8]) for i in range(n)]
+    rows = [tuple(buf[16*i:16*i+16]) for i in range(n)]
     rows = [r for r in rows if r[0] > 0]
     med = lambda f: statistics.median(f(x) for x in rows)
     print(f"workgroups {len(rows)}: items {med(lambda x: x[0]):.0f}, steps {med(lambda x: x[1]):.0f}, total {med(lambda x: x[4]):.0f} ticks "
           f"(min {min(x[4] for x in rows)}, max {max(x[4] for x in rows)})  [s_memtime ticks, wave 0, medians over workgroups]")
     print(f"per step: {med(lambda x: x[4]/x[1]):.0f} total | vmcnt wait {med(lambda x: x[2]/x[1]):.0f} | barrier wait {med(lambda x: x[3]/x[1]):.0f} | "
           f"clean step body {med(lambda x: x[6]/max(1,x[7])):.0f} ({med(lambda x: x[7]/x[1])*100:.0f}% of steps)")
-    print(f"per item: epilogue (scale, RoPE, bf16, next K/V request, stores, wait) {med(lambda x: x[5]/x[0]):.0f}")
+    print(f"per item: epilogue {med(lambda x: x[5]/x[0]):.0f} = scale/RoPE/bf16 {med(lambda x: x[8]/x[0]):.0f} + next K/V request {med(lambda x: x[9]/x[0]):.0f} "
+          f"+ swaps/stores {med(lambda x: x[10]/x[0]):.0f} + counted wait {med(lambda x: (x[5]-x[8]-x[9]-x[10])/x[0]):.0f}")
+    print(f"masked / partial steps: {med(lambda x: x[11]/max(1,x[1]-x[7])):.0f} per step ({med(lambda x: (x[1]-x[7])/x[1])*100:.0f}% of steps)")
     tot = sum(x[4] for x in rows)
     sh = lambda k: 100 * sum(x[k] for x in rows) / tot
     print("shares of workgroup time: vmcnt waits %.1f%%, barrier waits %.1f%%, clean bodies %.1f%%, item epilogues %.1f%%" % (sh(2), sh(3), sh(6), sh(5)))
