@@ -110,38 +110,34 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv4_kernel(AttnArgs a, int 
             off_tr2[dt] = r2 * (D * 2) + ((ch ^ swz<D, KIND_ROW>(r2)) << 4) + sub;
         }
     }
-    // per-lane byte offset inside one 1-KiB piece of a 64-row tile (4 rows of 16 swizzled 16-B chunks): piece t of this wave
-    // covers rows (4 wave + t) * 4 .. + 3; the row part of a piece goes into its scalar base, and because the swizzle of
-    // row r is ((r & 3) << 2) | ((r >> 2) & 3) the pieces differ only by chunk ^ t, i.e. byte offset ^ 16 t (the row
-    // strides are multiples of 32 elements — checked by the launcher — so bits 4, 5 of the offset are the chunk's)
-    const unsigned q_off0 = (unsigned)((lane >> 4) * a.ld + ((lane & 15) ^ ((lane >> 4) << 2)) * 8) * 2u;
-    const unsigned do_off0 = (unsigned)((lane >> 4) * a.lddo + ((lane & 15) ^ ((lane >> 4) << 2)) * 8) * 2u;
     const unsigned lds_base = (unsigned)(uintptr_t)(MMU_LDS char*)smem;
     const float c = a.scale * LOG2E;
 
     // ---- the DMA cursor: the stage that is issued next (all wave-uniform).  Past the last stage of the last item it
     // stays where it is: the pieces then re-read that stage into a ring slot nobody reads, which keeps the issue and the
     // counted waits free of branches.
-    int d_item = blockIdx.x, d_pr, d_pr1, issued = 0;
+    int d_item = blockIdx.x, d_pr, d_pr1, issued = 0, gs_started = 0;
     const bf16* d_q;
     const bf16* d_do;
     const float* d_lse;
     const float* d_dl;
-    // per stage (dma_stage): this wave's first piece of the Q / dO tile, its 32 row constants, its LDS addresses
+    // per stage (dma_stage): this wave's 16 rows of the Q / dO tile, its row constants, its LDS addresses
     const char* s_q;
     const char* s_do;
     const float* s_rc;
     unsigned s_lds, s_lds_rc;
-    bool s_full;
-    const size_t pstride_q = (size_t)a.ld * 8, pstride_do = (size_t)a.lddo * 8;  // 4 rows, bytes
+    int s_lim, s_rows;
+    const unsigned ldq2 = (unsigned)a.ld * 2u, lddo2 = (unsigned)a.lddo * 2u;  // row strides in bytes (< 2^24: launcher)
     auto dma_stage = [&]() {
         const int row0 = d_pr * 64;
-        s_full = row0 + 64 <= S;
-        s_q = reinterpret_cast<const char*>(d_q + (size_t)(row0 + wave * 16) * a.ld);
-        s_do = reinterpret_cast<const char*>(d_do + (size_t)(row0 + wave * 16) * a.lddo);
-        s_rc = (wave < 2 ? d_lse : d_dl) + row0 + (wave & 1) * 32;
-        s_lds = lds_base + (issued % NST) * STB + wave * 4096;
-        s_lds_rc = lds_base + ROWC + ((issued % NST) * 128 + (wave >> 1) * 64 + (wave & 1) * 32) * 4;
+        const int wrow = min(row0 + wave * 16, S - 1);  // this wave's first row, kept inside the sequence
+        s_q = reinterpret_cast<const char*>(d_q + (size_t)wrow * a.ld);
+        s_do = reinterpret_cast<const char*>(d_do + (size_t)wrow * a.lddo);
+        s_lim = S - 1 - wrow;  // rows wrow + 0 .. s_lim exist (>= 15 on a full stage)
+        s_rows = S - row0;     // row constants that exist (>= 64 on a full stage)
+        s_rc = ((wave & 1) ? d_dl : d_lse) + row0;  // waves 0, 2: the 64 lse2 values; waves 1, 3: the 64 deltas (twice each:
+        s_lds = lds_base + (issued % NST) * STB + wave * 4096;  // the same bytes to the same place, and no lane predicate)
+        s_lds_rc = lds_base + ROWC + ((issued % NST) * 128 + (wave & 1) * 64) * 4;
     };
     auto dma_open = [&](int v) {
         int kvb, hh, b;
@@ -156,36 +152,23 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv4_kernel(AttnArgs a, int 
     };
     dma_open(d_item);
     dma_stage();
-    // a ragged stage (the last rows of a sequence that is not a multiple of 64): all nine pieces at once, per-lane
-    // addresses; rows past the sequence re-read row S-1 (their lse2 is +inf: P = 0 exactly)
-    auto dma_ragged_stage = [&]() {
-        const int row0 = d_pr * 64;
-#pragma unroll
-        for (int p = 0; p < 8; ++p) {
+    // piece p (0..3 Q, 4..7 dO, 8 row constants) of the cursor's stage: straight-line code, the same for a full stage and
+    // for the ragged last stage of a sequence that is not a multiple of 64 (a branch would cut the MFMA regions the
+    // pieces sit between into basic blocks).  Rows past the sequence re-read row S-1 and take their lse2 from the +inf
+    // page, so P = 0 exactly for them.
+    const int rr4 = lane >> 4;
+    const unsigned chunk0 = (unsigned)(((lane & 15) ^ (rr4 << 2)) << 4);
+    auto dma_piece = [&](int p) {
+        if (p < 8) {
             const int t = p & 3;
             const bool is_do = p >= 4;
-            const int ld = is_do ? a.lddo : a.ld;
-            const int row = min(row0 + (wave * 4 + t) * 4 + (lane >> 4), S - 1);
-            const bf16* src = (is_do ? d_do : d_q) + (size_t)row * ld + ((((lane & 15) ^ ((lane >> 4) << 2)) ^ t) << 3);
-            glds16_asm(src, __builtin_amdgcn_readfirstlane(s_lds + (is_do ? TB : 0) + t * 1024));
-        }
-        if (lane < 32) {
-            const int qr = row0 + (wave & 1) * 32 + lane;
-            const float* src = wave < 2 ? (qr < S ? d_lse + qr : reinterpret_cast<const float*>(mmu_inf16))
-                                        : (qr < S ? d_dl + qr : reinterpret_cast<const float*>(mmu_zero16));
+            const unsigned row = (unsigned)min(4 * t + rr4, s_lim);
+            const unsigned voff = row * (is_do ? lddo2 : ldq2) + (chunk0 ^ (unsigned)(t << 4));
+            glds16_sv(is_do ? s_do : s_q, voff, s_lds + (is_do ? TB : 0) + t * 1024);
+        } else {
+            const float* src = lane < s_rows ? s_rc + lane : reinterpret_cast<const float*>((wave & 1) ? mmu_zero16 : mmu_inf16);
             glds4_asm(src, __builtin_amdgcn_readfirstlane(s_lds_rc));
         }
-    };
-    // piece p (0..3 Q, 4..7 dO, 8 row constants: waves 0,1 lse2 rows [0,32) / [32,64), waves 2,3 delta likewise) of the
-    // cursor's stage
-    auto dma_piece = [&](int p) {
-        if (!s_full) {
-            if (p == 0) dma_ragged_stage();
-            return;
-        }
-        if (p < 4) glds16_sv(s_q + p * pstride_q, q_off0 ^ (unsigned)(p << 4), s_lds + p * 1024);
-        else if (p < 8) glds16_sv(s_do + (p - 4) * pstride_do, do_off0 ^ (unsigned)((p - 4) << 4), s_lds + TB + (p - 4) * 1024);
-        else if (lane < 32) glds4_lane(s_rc, s_lds_rc);
     };
     auto dma_advance = [&]() {
         ++issued;
@@ -193,11 +176,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv4_kernel(AttnArgs a, int 
         else if (d_item + G < n_items) { d_item += G; dma_open(d_item); }
         dma_stage();
     };
-    bool in_steps = false;
     auto dma_pieces = [&](int p0, int n) {
 #pragma unroll
-        for (int p = p0; p < p0 + n; ++p)
-            if (!((DKDV4_EXP & 1) && in_steps)) dma_piece(p);
+        for (int q = p0; q < p0 + n; ++q)
+            if (!(DKDV4_EXP & 1) || gs_started == 0) dma_piece(q);
         if (p0 + n == 9) dma_advance();
     };
 #pragma unroll
@@ -227,7 +209,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv4_kernel(AttnArgs a, int 
     __builtin_amdgcn_s_waitcnt(waitcnt_vm(0));
 
     f32x16 dk[NDT], dv[NDT];
-    in_steps = true;
+    gs_started = 1;
     const MMU_LDS char* lds0 = (const MMU_LDS char*)smem;
     int gs = 0;  // steps done by this workgroup = index of the stage the next step reads
 
@@ -260,10 +242,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv4_kernel(AttnArgs a, int 
 #endif
             const MMU_LDS char* qt = lds0 + buf * STB;  // wave-uniform stage base (one scalar add per address below)
             const MMU_LDS float* rc = (const MMU_LDS float*)(smem + ROWC) + buf * 128;
-            const bool act0 = pr * 64 < S && (!CAUSAL || (pr * 64 + 31 >= key0));
-            const bool act1 = pr * 64 + 32 < S && (!CAUSAL || (pr * 64 + 63 >= key0));
 #define SB() __builtin_amdgcn_sched_barrier(0)
 #define SG(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+// keeps the values computed in a region in that region (hipcc otherwise sinks a region's VALU work into the block of its
+// first use, behind the next branch, where nothing overlaps it)
+#define PIN8(v) asm volatile("" ::"v"(v))
             // Q row fragments and lse2 of a tile (requested one region ahead of its S chain)
             auto load_rows = [&](int half, bf16x8(&fq)[NKS], f32x4(&l)[4]) {
                 const MMU_LDS char* qtile = qt + half * 32 * (D * 2);
@@ -274,135 +257,119 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv4_kernel(AttnArgs a, int 
 #pragma unroll
                 for (int g = 0; g < 4; ++g) l[g] = *(const MMU_LDS f32x4*)(rc + half * 32 + 8 * g + 4 * hl);
             };
-            // One 32-row query tile against this wave's 32 keys, four scheduling regions of 8 MFMAs each; every region
-            // carries the LDS reads of a LATER region and the VALU work of an EARLIER one between its MFMAs:
+            // One 32-row query tile against this wave's 32 keys: ONE body for every kind of tile (a second instantiation
+            // made hipcc keep the dK / dV accumulators in different registers per path and copy all 128 at every merge).
+            // Four scheduling regions of 8 MFMAs each; every region carries the LDS reads of a LATER region and the VALU
+            // work of an EARLIER one between its MFMAs:
             //   R1  S = Q K^T chain          | transposed dO^T fragments of rows 0..15, dO row fragments
-            //   R2  dP = dO V^T chain        | P = exp2(S c - lse2), its bf16 fragments | transposed dO^T, rows 16..31, delta
-            //   R3  dV^T += dO^T P           | dS = P (dP - delta) and its bf16 fragments | transposed Q^T fragments
-            //   R4  dK^T += Q^T dS           | Q row fragments + lse2 of the NEXT tile (next >= 0)
-            // DMA pieces p0 .. p0+np-1 of the stage three steps ahead go out at the region boundaries.
-            // MASKED: causal diagonal / padded keys: rows below `kd2 + 4 hl` (per lane) get P = 0.
-            auto tile = [&](auto masked_c, int half, int next, int p0, int np, bf16x8(&fq)[NKS], f32x4(&l)[4]) {
-                constexpr bool MASKED = decltype(masked_c)::value;
+            //   R2  dP = dO V^T chain        | P = exp2(S c - lse2) | transposed dO^T, rows 16..31, delta
+            //       (masked tiles only: P = 0 on the rows above the diagonal / for padded keys; a short block of its own)
+            //   R3  dV^T += dO^T P           | bf16 P, dS = P (dP - delta) and its bf16 fragments | transposed Q^T fragments
+            //   R4  dK^T += Q^T dS           | Q row fragments + lse2 of the NEXT tile (half 0 only)
+            auto tile = [&](int half, bool prefetch_next, int p0, int np, bf16x8(&fq)[NKS], f32x4(&l)[4]) {
                 const MMU_LDS char* qtile = qt + half * 32 * (D * 2);
                 bf16x8 to[NDT], tq[NDT], to2[NDT], tq2[NDT], fo[NKS];
                 f32x4 d[4];
                 f32x16 sv, dpv;
-                int kd2 = 0;
-                if (MASKED) {
-                    const int q_first = pr * 64 + half * 32;
-                    const bool diag = CAUSAL && (q_first < key0 + 31);
-                    kd2 = !kvalid ? 1000 : (diag ? key - q_first - 4 * hl : -1000);  // row 8g+j masked iff 8g+j < kd2
-                }
+                const int q_first = pr * 64 + half * 32;
+                const bool diag = CAUSAL && (q_first < key0 + 31);
+                const bool masked = diag || !all_valid;  // wave-uniform
+                // DMA pieces p0 .. p0+np-1 of the stage three steps ahead go out at the region boundaries.
+                // Every MFMA gap is a scheduling region of its own (sched_barrier after each): what overlaps which MFMA
+                // is written down here, not left to the scheduler's grouping heuristics.
                 const int n1 = np > 0 ? 1 : 0, n2 = np > 1 ? 1 : 0, n3 = np > 2 ? 1 : 0, n4 = np > 3 ? np - 3 : 0;
                 dma_pieces(p0, n1);
                 // ---- R1
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sv[r] = 0.f;
 #pragma unroll
-                for (int ks = 0; ks < NKS; ++ks) sv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[ks], kf[ks], sv, 0, 0, 0);
-#pragma unroll
-                for (int dt = 0; dt < NDT; ++dt) {
-                    if (DKDV4_EXP & 4) { to[dt] = kf[dt]; continue; }
-                    to[dt] = tr_load(qtile + TB + off_tr1[dt], qtile + TB + off_tr2[dt]);
+                for (int ks = 0; ks < NKS; ++ks) {
+                    sv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[ks], kf[ks], sv, 0, 0, 0);
+                    if (!(ks & 1)) {
+                        const int dt = ks >> 1;
+                        to[dt] = (DKDV4_EXP & 4) ? kf[dt] : tr_load(qtile + TB + off_tr1[dt], qtile + TB + off_tr2[dt]);
+                    }
+                    fo[ks] = (DKDV4_EXP & 16) ? kf[ks] : *(const MMU_LDS bf16x8*)(qtile + TB + off_row[ks]);
+                    SB();
                 }
-#pragma unroll
-                for (int ks = 0; ks < NKS; ++ks)
-                    if (!(DKDV4_EXP & 16)) fo[ks] = *(const MMU_LDS bf16x8*)(qtile + TB + off_row[ks]);
-                    else fo[ks] = kf[ks];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) { SG(0x8, 1); SG(0x100, 2); }
-                SB();
                 dma_pieces(p0 + n1, n2);
                 // ---- R2
 #pragma unroll
                 for (int r = 0; r < 16; ++r) dpv[r] = 0.f;
 #pragma unroll
-                for (int ks = 0; ks < NKS; ++ks) dpv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fo[ks], vf[ks], dpv, 0, 0, 0);
+                for (int ks = 0; ks < NKS; ++ks) {
+                    dpv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fo[ks], vf[ks], dpv, 0, 0, 0);
+                    if (!(DKDV4_EXP & 2)) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if (DKDV4_EXP & 2) continue;
-                        const float pv = fast_exp2(__builtin_fmaf(sv[4 * g + j], c, -l[g][j]));
-                        sv[4 * g + j] = (MASKED && (8 * g + j < kd2)) ? 0.f : pv;
+                        for (int e = 2 * ks; e < 2 * ks + 2; ++e) sv[e] = fast_exp2(__builtin_fmaf(sv[e], c, -l[e >> 2][e & 3]));
+                        asm volatile("" : "+v"(sv[2 * ks]), "+v"(sv[2 * ks + 1]));  // the slice stays in this gap (see PIN8)
                     }
-                const bf16x8 pf = pack8(sv, 0), pf2 = pack8(sv, 1);
-#pragma unroll
-                for (int dt = 0; dt < NDT; ++dt) {
-                    if (DKDV4_EXP & 4) { to2[dt] = kf[4 + dt]; continue; }
-                    to2[dt] = tr_load(qtile + 16 * (D * 2) + TB + off_tr1[dt], qtile + 16 * (D * 2) + TB + off_tr2[dt]);
+                    if (ks < 4) to2[ks] = (DKDV4_EXP & 4) ? kf[4 + ks]
+                                                          : tr_load(qtile + 16 * (D * 2) + TB + off_tr1[ks], qtile + 16 * (D * 2) + TB + off_tr2[ks]);
+                    else d[ks - 4] = *(const MMU_LDS f32x4*)(rc + 64 + half * 32 + 8 * (ks - 4) + 4 * hl);
+                    SB();
                 }
+                if (masked) {  // row 8g + 4hl + j of this tile is masked for this lane's key iff 8g + j < kd2
+                    const int kd2 = !kvalid ? 1000 : (diag ? key - q_first - 4 * hl : -1000);
 #pragma unroll
-                for (int g = 0; g < 4; ++g) d[g] = *(const MMU_LDS f32x4*)(rc + 64 + half * 32 + 8 * g + 4 * hl);
+                    for (int g = 0; g < 4; ++g)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { SG(0x8, 1); SG(0x100, 2); SG(0x2, MASKED ? 10 : 7); }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { SG(0x8, 1); SG(0x100, 1); SG(0x2, MASKED ? 10 : 7); }
-                SB();
+                        for (int j = 0; j < 4; ++j) sv[4 * g + j] = (8 * g + j < kd2) ? 0.f : sv[4 * g + j];
+                }
                 dma_pieces(p0 + n1 + n2, n3);
                 // ---- R3
-#pragma unroll
-                for (int dt = 0; dt < NDT; ++dt) dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(to[dt], pf, dv[dt], 0, 0, 0);
-#pragma unroll
-                for (int dt = 0; dt < NDT; ++dt) dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(to2[dt], pf2, dv[dt], 0, 0, 0);
-#pragma unroll
-                for (int dt = 0; dt < NDT; ++dt) {
-                    if (DKDV4_EXP & 4) { tq[dt] = vf[dt]; tq2[dt] = vf[4 + dt]; continue; }
-                    tq[dt] = tr_load(qtile + off_tr1[dt], qtile + off_tr2[dt]);
-                    tq2[dt] = tr_load(qtile + 16 * (D * 2) + off_tr1[dt], qtile + 16 * (D * 2) + off_tr2[dt]);
-                }
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (!(DKDV4_EXP & 2)) dpv[4 * g + j] = sv[4 * g + j] * (dpv[4 * g + j] - d[g][j]);
-                const bf16x8 dsf = pack8(dpv, 0), dsf2 = pack8(dpv, 1);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) { SG(0x8, 1); SG(0x100, 2); SG(0x2, 5); }
+                const bf16x8 pf = pack8(sv, 0);
+                bf16x8 pf2, dsf, dsf2;
                 SB();
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    if (i < 4) dv[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(to[i], pf, dv[i], 0, 0, 0);
+                    else dv[i - 4] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(to2[i - 4], pf2, dv[i - 4], 0, 0, 0);
+                    if (i == 0) { pf2 = pack8(sv, 1); asm volatile("" : "+v"(pf2)); }
+                    if (i < 4) tq[i] = (DKDV4_EXP & 4) ? vf[i] : tr_load(qtile + off_tr1[i], qtile + off_tr2[i]);
+                    else tq2[i - 4] = (DKDV4_EXP & 4) ? vf[i] : tr_load(qtile + 16 * (D * 2) + off_tr1[i - 4], qtile + 16 * (D * 2) + off_tr2[i - 4]);
+                    if (!(DKDV4_EXP & 2)) {
+#pragma unroll
+                        for (int e = 2 * i; e < 2 * i + 2; ++e) dpv[e] = sv[e] * (dpv[e] - d[e >> 2][e & 3]);
+                        asm volatile("" : "+v"(dpv[2 * i]), "+v"(dpv[2 * i + 1]));
+                    }
+                    if (i == 4) { dsf = pack8(dpv, 0); asm volatile("" : "+v"(dsf)); }
+                    SB();
+                }
                 dma_pieces(p0 + n1 + n2 + n3, n4);
                 // ---- R4
 #pragma unroll
-                for (int dt = 0; dt < NDT; ++dt) dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tq[dt], dsf, dk[dt], 0, 0, 0);
-#pragma unroll
-                for (int dt = 0; dt < NDT; ++dt) dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tq2[dt], dsf2, dk[dt], 0, 0, 0);
-                if (next >= 0) {
-                    load_rows(next, fq, l);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) { SG(0x8, 1); SG(0x100, 2); }
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) { SG(0x8, 1); SG(0x100, 1); }
+                for (int i = 0; i < 8; ++i) {
+                    if (i < 4) dk[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tq[i], dsf, dk[i], 0, 0, 0);
+                    else dk[i - 4] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tq2[i - 4], dsf2, dk[i - 4], 0, 0, 0);
+                    if (i == 0) { dsf2 = pack8(dpv, 1); asm volatile("" : "+v"(dsf2)); }
+                    if (prefetch_next) {  // compile-time after inlining: Q rows and lse2 of tile 1
+                        const MMU_LDS char* qn = qt + 32 * (D * 2);
+                        fq[i] = (DKDV4_EXP & 16) ? vf[i] : *(const MMU_LDS bf16x8*)(qn + off_row[i]);
+                        if (i < 4) l[i] = *(const MMU_LDS f32x4*)(rc + 32 + 8 * i + 4 * hl);
+                    }
+                    SB();
                 }
-                SB();
             };
             bf16x8 fq[NKS];
             f32x4 l4[4];
+            // Both tiles always run: a tile above the causal diagonal or past the sequence end contributes exact zeros (its
+            // P is masked / its lse2 is +inf), and the waves meet at the next barrier anyway, so skipping it would only
+            // bring branches (and with them a second kind of step) into the body.
+            load_rows(0, fq, l4);
+#ifdef MMU_ATTN_STAMP
             const bool clean = all_valid && !(CAUSAL && pr * 64 < key0 + 31) && pr * 64 + 32 < S;
-            if (clean) {  // both tiles active, nothing masked: the steady state
-                load_rows(0, fq, l4);
-                SB();
-                tile(std::false_type{}, 0, 1, 0, 5, fq, l4);
-                tile(std::false_type{}, 1, -1, 5, 4, fq, l4);
-#ifdef MMU_ATTN_STAMP
-                t_clean += stamp_now() - t_w2;
-                n_clean += 1;
 #endif
-            } else {
-                STAMP(t_m0);
-                dma_pieces(0, 9);
-                for (int half = 0; half < 2; ++half) {
-                    if (!(half ? act1 : act0)) continue;
-                    load_rows(half, fq, l4);
-                    SB();
-                    tile(std::true_type{}, half, -1, 0, 0, fq, l4);
-                }
+            SB();
+            tile(0, true, 0, 5, fq, l4);
+            tile(1, false, 5, 4, fq, l4);
 #ifdef MMU_ATTN_STAMP
-                t_masked += stamp_now() - t_m0;
+            if (clean) { t_clean += stamp_now() - t_w2; n_clean += 1; }
+            else t_masked += stamp_now() - t_w2;
 #endif
-            }
 #undef SB
 #undef SG
+#undef PIN8
         }
 
         // ---- the item's gradients: scale dK, transpose rotation of RoPE on the (d, d+64) pairs of dK (same arithmetic

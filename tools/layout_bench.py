@@ -29,7 +29,20 @@ cases = [
     ("transpose [M, 22016]", lambda: hip.transpose(gu, guT), 2 * 2 * I * M * B),
     ("torch copy [M, 22016] (reference stream)", lambda: cp.copy_(gu), 2 * 2 * I * M * B),
 ]
+HOT = "--hot" in sys.argv  # a burst of GEMMs in front of every timed launch: the power / clock state of the step
+if HOT:
+    ga = torch.randn(M, d, device=dev, generator=g).to(BF); gb = torch.randn(I, d, device=dev, generator=g).to(BF)
+    gc = torch.empty(M, I, device=dev, dtype=BF)
+def timed_hot(fn, n=5):
+    tot = 0.0
+    for _ in range(n):
+        for _ in range(6): hip.gemm(hip.NT, ga, gb, gc)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+        tot += e0.elapsed_time(e1)
+    return tot / n * 1e3
 def timed(fn, n=10):
+    if HOT: return timed_hot(fn)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(n): fn()
