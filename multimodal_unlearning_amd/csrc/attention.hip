@@ -732,9 +732,10 @@ int launch_bwd(const AttnArgs& a, hipStream_t s) {
                        a.lddo, const_cast<float*>(a.delta), a.lse, a.B, a.S, a.H);
     MMU_CHECK_LAUNCH();
     if constexpr (D == 128) {
-        // 4 waves x 512 registers, persistent, K / V in registers, 4-stage Q/dO ring (attention_dkdv4.hip); its DMA
-        // addressing wants row strides that are multiples of 32 elements
-        if (g_dkdv_variant == 4 && a.ld % 32 == 0 && a.lddo % 32 == 0) {
+        // 4 waves x 512 registers, persistent, K / V in registers, 4-stage Q/dO ring (attention_dkdv4.hip).  It takes
+        // sequences whose length is a multiple of 32 (each wave's 32 keys exist or none does: one unpredicated store
+        // path) and row strides that fit its 24-bit offset arithmetic; everything else goes to the eight-wave kernel.
+        if (g_dkdv_variant == 4 && a.S % 32 == 0 && a.ld < (1 << 23) && a.lddo < (1 << 23)) {
             const int e4 = mmu_internal_launch_dkdv4(&a, CAUSAL ? 1 : 0, s);
             if (e4) return e4;
             hipLaunchKernelGGL((attn_bwd_dq_kernel<D, CAUSAL>), dim3(((a.S + 127) / 128) * a.H * a.B), dim3(256), LDS_DQ, s, a);

@@ -204,14 +204,35 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv4_kernel(AttnArgs a, int 
         kvalid = key < S && (a.kmask == nullptr || a.kmask[rowbase + key] != 0);
     };
     load_kv(kvb, hh, b);
-    // the modelled wait tells the compiler that these loads have landed, or it would re-check them with
-    // s_waitcnt vmcnt(..0) inside the step loop and drain the ring with it
+    // The modelled wait tells the compiler that these loads have landed, and the empty statement that "rewrites" the
+    // fragments makes it settle every wait it still wants for them HERE: without it hipcc re-checks the loads with
+    // s_waitcnt vmcnt(15) .. vmcnt(0) in front of the first MFMAs of every step and drains the DMA ring each time.
+    auto settle_kv = [&]() {
+        asm volatile("" : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[3]), "+v"(kf[4]), "+v"(kf[5]), "+v"(kf[6]), "+v"(kf[7]),
+                          "+v"(vf[0]), "+v"(vf[1]), "+v"(vf[2]), "+v"(vf[3]), "+v"(vf[4]), "+v"(vf[5]), "+v"(vf[6]), "+v"(vf[7]));
+    };
     __builtin_amdgcn_s_waitcnt(waitcnt_vm(0));
+    settle_kv();
 
     f32x16 dk[NDT], dv[NDT];
     gs_started = 1;
     const MMU_LDS char* lds0 = (const MMU_LDS char*)smem;
     int gs = 0;  // steps done by this workgroup = index of the stage the next step reads
+
+    // The barrier that opens step gs+1 ("every wave's pieces of stage gs+1 are in LDS; slot gs%NST is free") sits in front
+    // of the LAST MFMA region of step gs, whose LDS reads are then already the first row fragments of step gs+1: a step
+    // starts on its first MFMA with nothing outstanding.  The first step of the workgroup is opened here.
+    bf16x8 fq[NKS];
+    f32x4 l4[4];
+    asm volatile("s_waitcnt vmcnt(18)" ::: "memory");  // stage 0 has landed (stages 1, 2 may be outstanding)
+    __builtin_amdgcn_s_barrier();
+    {
+        const MMU_LDS float* rc0 = (const MMU_LDS float*)(smem + ROWC);
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) fq[ks] = *(const MMU_LDS bf16x8*)(lds0 + off_row[ks]);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) l4[g] = *(const MMU_LDS f32x4*)(rc0 + 8 * g + 4 * hl);
+    }
 
     for (int item = blockIdx.x; item < n_items; item += G) {
         const int key0 = kvb * 128 + wave * 32;
@@ -225,38 +246,20 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv4_kernel(AttnArgs a, int 
         const int pr1 = (S + 63) / 64;
 
         for (int pr = pr0; pr < pr1; ++pr, ++gs) {
-            const int buf = gs % NST;
-            // stage `gs` has landed when at most the pieces of the stages issued after it are outstanding
-            const int ahead = issued - 1 - gs;
-            STAMP(t_w0);
-            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            STAMP(t_w1);
-            __builtin_amdgcn_s_barrier();  // every wave's pieces of stage `gs` are in LDS; slot (gs-1)%NST is free
+            const int buf = gs % NST, nbuf = (gs + 1) % NST;
             STAMP(t_w2);
 #ifdef MMU_ATTN_STAMP
-            t_vm += t_w1 - t_w0;
-            t_bar += t_w2 - t_w1;
             n_steps += 1;
 #endif
             const MMU_LDS char* qt = lds0 + buf * STB;  // wave-uniform stage base (one scalar add per address below)
             const MMU_LDS float* rc = (const MMU_LDS float*)(smem + ROWC) + buf * 128;
+            const MMU_LDS char* qt_next = lds0 + nbuf * STB;
+            const MMU_LDS float* rc_next = (const MMU_LDS float*)(smem + ROWC) + nbuf * 128;
 #define SB() __builtin_amdgcn_sched_barrier(0)
 #define SG(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 // keeps the values computed in a region in that region (hipcc otherwise sinks a region's VALU work into the block of its
 // first use, behind the next branch, where nothing overlaps it)
 #define PIN8(v) asm volatile("" ::"v"(v))
-            // Q row fragments and lse2 of a tile (requested one region ahead of its S chain)
-            auto load_rows = [&](int half, bf16x8(&fq)[NKS], f32x4(&l)[4]) {
-                const MMU_LDS char* qtile = qt + half * 32 * (D * 2);
-#pragma unroll
-                for (int ks = 0; ks < NKS; ++ks)
-                    if (!(DKDV4_EXP & 16)) fq[ks] = *(const MMU_LDS bf16x8*)(qtile + off_row[ks]);
-                    else fq[ks] = vf[ks];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) l[g] = *(const MMU_LDS f32x4*)(rc + half * 32 + 8 * g + 4 * hl);
-            };
             // One 32-row query tile against this wave's 32 keys: ONE body for every kind of tile (a second instantiation
             // made hipcc keep the dK / dV accumulators in different registers per path and copy all 128 at every merge).
             // Four scheduling regions of 8 MFMAs each; every region carries the LDS reads of a LATER region and the VALU
@@ -266,7 +269,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv4_kernel(AttnArgs a, int 
             //       (masked tiles only: P = 0 on the rows above the diagonal / for padded keys; a short block of its own)
             //   R3  dV^T += dO^T P           | bf16 P, dS = P (dP - delta) and its bf16 fragments | transposed Q^T fragments
             //   R4  dK^T += Q^T dS           | Q row fragments + lse2 of the NEXT tile (half 0 only)
-            auto tile = [&](int half, bool prefetch_next, int p0, int np, bf16x8(&fq)[NKS], f32x4(&l)[4]) {
+            auto tile = [&](int half, int p0, int np, bf16x8(&fq)[NKS], f32x4(&l)[4]) {
                 const MMU_LDS char* qtile = qt + half * 32 * (D * 2);
                 bf16x8 to[NDT], tq[NDT], to2[NDT], tq2[NDT], fo[NKS];
                 f32x4 d[4];
@@ -337,32 +340,43 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv4_kernel(AttnArgs a, int 
                     SB();
                 }
                 dma_pieces(p0 + n1 + n2 + n3, n4);
-                // ---- R4
+                // ---- R4 (tile 0: next = tile 1 of this stage; tile 1: next = tile 0 of the next stage, behind the
+                // barrier that opens the next step: this step's stage is not read after this point)
+                const MMU_LDS char* qn = half == 0 ? qt + 32 * (D * 2) : qt_next;
+                const MMU_LDS float* rn = half == 0 ? rc + 32 : rc_next;
+                if (half == 1) {
+#ifdef MMU_ATTN_STAMP
+                    const unsigned long long t_b0 = stamp_now();
+#endif
+                    asm volatile("s_waitcnt vmcnt(18)" ::: "memory");  // stage gs+1 has landed (gs+2, gs+3 may be outstanding)
+#ifdef MMU_ATTN_STAMP
+                    const unsigned long long t_b1 = stamp_now();
+#endif
+                    __builtin_amdgcn_s_barrier();
+#ifdef MMU_ATTN_STAMP
+                    const unsigned long long t_b2 = stamp_now();
+                    t_vm += t_b1 - t_b0;
+                    t_bar += t_b2 - t_b1;
+#endif
+                }
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     if (i < 4) dk[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tq[i], dsf, dk[i], 0, 0, 0);
                     else dk[i - 4] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tq2[i - 4], dsf2, dk[i - 4], 0, 0, 0);
                     if (i == 0) { dsf2 = pack8(dpv, 1); asm volatile("" : "+v"(dsf2)); }
-                    if (prefetch_next) {  // compile-time after inlining: Q rows and lse2 of tile 1
-                        const MMU_LDS char* qn = qt + 32 * (D * 2);
-                        fq[i] = (DKDV4_EXP & 16) ? vf[i] : *(const MMU_LDS bf16x8*)(qn + off_row[i]);
-                        if (i < 4) l[i] = *(const MMU_LDS f32x4*)(rc + 32 + 8 * i + 4 * hl);
-                    }
+                    fq[i] = (DKDV4_EXP & 16) ? vf[i] : *(const MMU_LDS bf16x8*)(qn + off_row[i]);
+                    if (i < 4) l[i] = *(const MMU_LDS f32x4*)(rn + 8 * i + 4 * hl);
                     SB();
                 }
             };
-            bf16x8 fq[NKS];
-            f32x4 l4[4];
             // Both tiles always run: a tile above the causal diagonal or past the sequence end contributes exact zeros (its
             // P is masked / its lse2 is +inf), and the waves meet at the next barrier anyway, so skipping it would only
             // bring branches (and with them a second kind of step) into the body.
-            load_rows(0, fq, l4);
 #ifdef MMU_ATTN_STAMP
             const bool clean = all_valid && !(CAUSAL && pr * 64 < key0 + 31) && pr * 64 + 32 < S;
 #endif
-            SB();
-            tile(0, true, 0, 5, fq, l4);
-            tile(1, false, 5, 4, fq, l4);
+            tile(0, 0, 5, fq, l4);
+            tile(1, 5, 4, fq, l4);
 #ifdef MMU_ATTN_STAMP
             if (clean) { t_clean += stamp_now() - t_w2; n_clean += 1; }
             else t_masked += stamp_now() - t_w2;
@@ -430,18 +444,21 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv4_kernel(AttnArgs a, int 
         STAMP(t_e1);
         // the next item's K / V (and key mask) are requested BEFORE this item's stores go out; the wait in front of the
         // next item's first step then only has to leave the stores outstanding
+        // (unconditionally: after the last item the current one is simply requested again — with the request, the wait
+        // and the statement that settles it on ONE path the compiler's count of what is outstanding is exact; behind an
+        // `if (more)` its structurised control flow lost track and every step re-checked the 16 loads)
         const bool more = item + G < n_items;
-        if (more) {
-            decode_wg_at(item + G, nx, a.H, a.B, false, kvb, hh, b);
-            if (!((DKDV4_EXP & 32) && a.scale != 12345.f)) load_kv(kvb, hh, b);
-        }
+        decode_wg_at(more ? item + G : item, nx, a.H, a.B, false, kvb, hh, b);
+        if (!((DKDV4_EXP & 32) && a.scale != 12345.f)) load_kv(kvb, hh, b);
         STAMP(t_e2);
         // Stores: a wave instruction that writes "one key per lane" touches 32 rows (32 B each) and costs ~440 cycles of
         // issue (measured: 7.1 k cycles for the 16 of an item); instead each half matrix (32 keys x 64 d) goes through a
         // 4-KiB LDS area private to the wave — 8 ds_write_b64 in, 4 ds_read_b128 out with 8 lanes per key — so a store
         // instruction writes 8 whole 128-B lines.  [key][16 granules of 8 B], granule ^= ((key >> 1) & 3) << 1.
+        // One straight path of unpredicated stores: with a per-row predicate (and its skip branches) hipcc could no longer
+        // tell what is outstanding at the seam and re-checked the next item's K / V loads in every step of the loop.
         const bool stores = key0 < S;  // wave-uniform
-        if (stores && !((DKDV4_EXP & 8) && a.scale != 12345.f)) {  // (the experiment keeps the stores reachable: no DCE)
+        auto store_all = [&]() {
             MMU_LDS char* xw = (MMU_LDS char*)smem + XLDS + wave * 4096;
             int lane_e = lane;
             asm volatile("" : "+v"(lane_e));  // keeps the address arithmetic below here (hoisted to the item's top it was spilled)
@@ -463,21 +480,25 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv4_kernel(AttnArgs a, int 
 #pragma unroll
                     for (int i = 0; i < 4; ++i) rows[i] = *(const MMU_LDS u32x4*)(xw + r0 + i * 1024);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        if (key0 + i * 8 + rr < S) *reinterpret_cast<u32x4*>(gp + (size_t)i * 8 * a.ldg + h * 64) = rows[i];
+                    for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(gp + (size_t)i * 8 * a.ldg + h * 64) = rows[i];
                 }
             }
-        }
+        };
+        const bool do_stores = !((DKDV4_EXP & 8) && a.scale != 12345.f);  // (the experiment keeps the stores reachable: no DCE)
+        // the launcher only takes this kernel for S % 32 == 0: a wave's 32 keys exist or none of them does
+        if (stores && do_stores) store_all();
         STAMP(t_e3);
-        if (more) {
-            if (stores) __builtin_amdgcn_s_waitcnt(waitcnt_vm(DKDV4_STORES));
-            else __builtin_amdgcn_s_waitcnt(waitcnt_vm(0));
-        }
+        // (a full drain, not vmcnt(DKDV4_STORES): with stores still outstanding hipcc guards every register they read
+        // against reuse, which puts s_waitcnt vmcnt(11) .. vmcnt(0) into the step loop — a drain of the DMA ring in EVERY step)
+        __builtin_amdgcn_s_waitcnt(waitcnt_vm(0));
+        settle_kv();
+#ifdef MMU_ATTN_STAMP
+        t_e_st += t_e3 - t_e2;
+#endif
 #ifdef MMU_ATTN_STAMP
         t_epi += stamp_now() - t_e0;
         t_e_math += t_e1 - t_e0;
         t_e_kv += t_e2 - t_e1;
-        t_e_st += t_e3 - t_e2;
         n_it += 1;
 #endif
     }

@@ -191,7 +191,12 @@ def test_attn_fwd_left_pad_mask(dev):
                                                 (2, 2, 333, False, 0, 128), (2, 2, 150, True, 20, 128),
                                                 (2, 3, 577, False, 0, 64), (1, 2, 130, True, 0, 64), (2, 2, 70, False, 9, 64),
                                                 (2, 4, 333, True, 0, 128), (1, 8, 1088, True, 0, 128),
-                                                (3, 8, 300, True, 37, 128), (2, 8, 450, False, 0, 128)])
+                                                (3, 8, 300, True, 37, 128), (2, 8, 450, False, 0, 128),
+                                                # multiples of 32 (the four-wave kernel's domain): ragged last 64-row stage,
+                                                # key blocks with waves that own no key, padding, several items per workgroup
+                                                (2, 4, 96, True, 0, 128), (3, 8, 288, True, 37, 128),
+                                                (2, 8, 416, False, 0, 128), (1, 16, 160, True, 5, 128),
+                                                (2, 8, 32, True, 0, 128)])
 @pytest.mark.parametrize("variant", [(8, 0), (4, 0), (4, 8)], ids=["w8", "w4", "w4-grid8"])
 def test_attn_bwd(dev, B, H, S, causal, pad, D, variant):
     # (4, 8): the persistent four-wave kernel on 8 workgroups, so every workgroup walks several items (seams, ring
