@@ -60,10 +60,21 @@ constexpr int waitcnt_vm(int n) { return (n & 15) | ((n >> 4) << 14) | 0x0F70; }
 // are already landing, so there is no per-item prologue (measured on the one-item-per-workgroup version of this
 // kernel: prologue 8.7 k + store tail 10.6 k cycles of a 69 k-cycle average workgroup, tools/attn_stamps.py --dkdv4).
 // The nine DMA pieces a wave contributes to a stage are issued at the boundaries of the MFMA regions of a step, not
-// in a burst at its top; the next item's K / V fragments are requested before the current item's stores are issued
-// and are waited for by count.
-// Per 32-row query tile four scheduling regions of 8 MFMAs each carry the LDS reads of a later region and the VALU
-// work of an earlier one (sched_group_barrier), see `tile` below.
+// in a burst at its top (branch-free: the same code for full and ragged stages).  The barrier that opens a step sits in
+// front of the last MFMA region of the previous one, whose LDS reads are already the next step's first row fragments.
+// Per 32-row query tile there is ONE body (both tiles of a step always run; masked tiles zero their P in a short block
+// of their own) made of four regions of 8 MFMAs; every MFMA gap is its own scheduling region with its slice of LDS reads
+// and VALU work pinned in it, see `tile` below.
+// At the end of an item each half matrix of dK / dV goes through a 4-KiB LDS area private to the wave so that a store
+// instruction writes 8 whole 128-B lines; the next item's K / V fragments are requested before those stores go out and
+// everything is drained once per item (a counted wait left hipcc guarding the stores' registers inside the step loop).
+// Sequence lengths that are not a multiple of 32 go to the eight-wave kernel (launch_bwd).
+// What the compiler must not be allowed to do here, each found the hard way (tools/attn_stamps.py, the .s):
+//  * two instantiations of the tile body -> dK / dV in different registers per path, 128 v_accvgpr_mov per step;
+//  * a branch between MFMA regions -> the VALU work of a region sinks into the next block, nothing overlaps it;
+//  * per-row predicated stores / `if (more)` around the next item's loads -> s_waitcnt vmcnt(15..0) in EVERY step
+//    (the structurised control flow hides what is outstanding), i.e. a drain of the DMA ring per step;
+//  * a value kept live for the DMA (lane * 4) -> spilled to scratch, reloaded behind vmcnt(0) in every step.
 // Measured reason for the rebuild (tools/attn_stamps.py on the 8-wave kernel): 5 850 cycles per iteration for 2 x 1 024
 // cycles of MFMA issue per SIMD, an epilogue worth 2.3 iterations (cross-wave partial sums through 128 KiB of LDS),
 // one workgroup per CU meeting at a barrier with the next stage only one iteration ahead.
@@ -72,7 +83,6 @@ constexpr int waitcnt_vm(int n) { return (n & 15) | ((n >> 4) << 14) | 0x0F70; }
 #define DKDV4_EXP 0  // LDS reads, 8 no stores, 16 no row LDS reads, 32 no K/V reload — results are garbage, addresses unchanged
 #endif
 constexpr int DKDV4_STAGES = 4;
-constexpr int DKDV4_STORES = 16;  // global stores per wave and item (8 x 16 B per lane for dK, 8 for dV)
 
 template <bool CAUSAL>
 __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv4_kernel(AttnArgs a, int n_items) {
@@ -488,7 +498,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv4_kernel(AttnArgs a, int 
         // the launcher only takes this kernel for S % 32 == 0: a wave's 32 keys exist or none of them does
         if (stores && do_stores) store_all();
         STAMP(t_e3);
-        // (a full drain, not vmcnt(DKDV4_STORES): with stores still outstanding hipcc guards every register they read
+        // (a full drain, not vmcnt(16 stores): with stores still outstanding hipcc guards every register they read
         // against reuse, which puts s_waitcnt vmcnt(11) .. vmcnt(0) into the step loop — a drain of the DMA ring in EVERY step)
         __builtin_amdgcn_s_waitcnt(waitcnt_vm(0));
         settle_kv();
