@@ -81,6 +81,15 @@ int mmu_attn_bwd_rope(const void* q, const void* k, const void* v, int ld, const
                       int B, int S, int H, int head_dim, float scale, int causal, const int* rope_pos,
                       const void* rope_cos, const void* rope_sin, void* stream);
 
+/* mmu_attn_bwd_rope that additionally leaves [dq | dk | dv]^T = dqkv_t [3 * H * head_dim][ldt] (ldt >= B * S, a multiple of
+ * 8; B * S a multiple of 8; dq / dk / dv 16-B aligned with ldg a multiple of 8): the A operand of the q|k|v weight
+ * gradient (mm/trainer.py backward of q_proj / k_proj / v_proj) without a transpose pass.  The persistent dK/dV kernel
+ * writes its two thirds itself; the rest is a strided transpose of the finished block. */
+int mmu_attn_bwd_rope_t(const void* q, const void* k, const void* v, int ld, const void* o, int ldo, const float* lse,
+                        const int* kmask, const void* dout, int lddo, float* delta, void* dq, void* dk, void* dv, int ldg,
+                        int B, int S, int H, int head_dim, float scale, int causal, const int* rope_pos,
+                        const void* rope_cos, const void* rope_sin, void* dqkv_t, int ldt, void* stream);
+
 /* dK/dV kernel of the head_dim-128 backward: low byte 8 = eight waves, K / V tiles in LDS; 4 = four waves (one per SIMD,
  * 512 registers), persistent, K / V fragments in registers, 4-stage Q/dO ring running across item seams.  Bits 8 and up:
  * workgroups of the four-wave kernel (0 = one per CU, else a multiple of 8).  Process-wide tuning / A-B switch. */

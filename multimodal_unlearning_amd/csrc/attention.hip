@@ -731,6 +731,14 @@ int launch_bwd(const AttnArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((attn_delta_kernel<D>), dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, a.o, a.ldo, a.dout,
                        a.lddo, const_cast<float*>(a.delta), a.lse, a.B, a.S, a.H);
     MMU_CHECK_LAUNCH();
+    // Transposed gradient copy (a.dT): the four-wave dK/dV kernel writes dk^T / dv^T itself; every other part goes through
+    // a strided transpose of the finished row-major block (same bytes as the caller's own transpose pass would move).
+    const int HD = a.H * D, M = a.B * a.S;
+    auto transpose_part = [&](int part, const bf16* src) -> int {
+        if (!a.dT) return 0;
+        return mmu_internal_transpose_strided(src, a.ldg, a.dT + (size_t)part * HD * a.ldt, a.ldt, M, HD, s);
+    };
+    bool kv_t_done = false;
     if constexpr (D == 128) {
         // 4 waves x 512 registers, persistent, K / V in registers, 4-stage Q/dO ring (attention_dkdv4.hip).  It takes
         // sequences whose length is a multiple of 32 (each wave's 32 keys exist or none does: one unpredicated store
@@ -738,15 +746,21 @@ int launch_bwd(const AttnArgs& a, hipStream_t s) {
         if (g_dkdv_variant == 4 && a.S % 32 == 0 && a.ld < (1 << 23) && a.lddo < (1 << 23)) {
             const int e4 = mmu_internal_launch_dkdv4(&a, CAUSAL ? 1 : 0, s);
             if (e4) return e4;
-            hipLaunchKernelGGL((attn_bwd_dq_kernel<D, CAUSAL>), dim3(((a.S + 127) / 128) * a.H * a.B), dim3(256), LDS_DQ, s, a);
-            MMU_CHECK_LAUNCH();
-            return 0;
+            kv_t_done = true;
         }
     }
-    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<D, CAUSAL>), dim3(((a.S + 127) / 128) * a.H * a.B), dim3(512), LDS_KV, s, a);
-    MMU_CHECK_LAUNCH();
+    if (!kv_t_done) {
+        hipLaunchKernelGGL((attn_bwd_dkdv_kernel<D, CAUSAL>), dim3(((a.S + 127) / 128) * a.H * a.B), dim3(512), LDS_KV, s, a);
+        MMU_CHECK_LAUNCH();
+    }
     hipLaunchKernelGGL((attn_bwd_dq_kernel<D, CAUSAL>), dim3(((a.S + 127) / 128) * a.H * a.B), dim3(256), LDS_DQ, s, a);
     MMU_CHECK_LAUNCH();
+    if (a.dT) {
+        int e = transpose_part(0, a.dq);
+        if (!e && !kv_t_done) e = transpose_part(1, a.dk);
+        if (!e && !kv_t_done) e = transpose_part(2, a.dv);
+        if (e) return e;
+    }
     return 0;
 }
 
@@ -793,11 +807,12 @@ extern "C" int mmu_attn_bwd(const void* q, const void* k, const void* v, int ld,
 
 // mmu_attn_bwd with the inverse RoPE rotation (gradient w.r.t. the un-rotated q, k) fused into the dq / dk stores;
 // rope_pos [B*S] int32, rope_cos / rope_sin [n_pos][64] bf16 (all three NULL: plain mmu_attn_bwd).
-extern "C" int mmu_attn_bwd_rope(const void* q, const void* k, const void* v, int ld, const void* o, int ldo,
-                                 const float* lse, const int* kmask, const void* dout, int lddo, float* delta,
-                                 void* dq, void* dk, void* dv, int ldg, int B, int S, int H, int head_dim, float scale,
-                                 int causal, const int* rope_pos, const void* rope_cos, const void* rope_sin,
-                                 void* stream) {
+// dqkv_t (may be NULL): additionally leaves [dq | dk | dv]^T = [3 * H * head_dim][ldt] (ldt >= B * S, a multiple of 8)
+// for the q|k|v weight gradient, i.e. what transposing the packed [B*S][3 * H * head_dim] gradient would give.
+static int attn_bwd_impl(const void* q, const void* k, const void* v, int ld, const void* o, int ldo, const float* lse,
+                         const int* kmask, const void* dout, int lddo, float* delta, void* dq, void* dk, void* dv, int ldg,
+                         int B, int S, int H, int head_dim, float scale, int causal, const int* rope_pos,
+                         const void* rope_cos, const void* rope_sin, void* dqkv_t, int ldt, void* stream) {
     AttnArgs a = {};
     a.rope_pos = rope_pos; a.rope_cos = (const bf16*)rope_cos; a.rope_sin = (const bf16*)rope_sin;
     if (rope_pos && (!rope_cos || !rope_sin)) return -1;
@@ -806,12 +821,35 @@ extern "C" int mmu_attn_bwd_rope(const void* q, const void* k, const void* v, in
     a.B = B; a.S = S; a.H = H; a.scale = scale;
     a.dout = (const bf16*)dout; a.lddo = lddo; a.delta = delta;
     a.dq = (bf16*)dq; a.dk = (bf16*)dk; a.dv = (bf16*)dv; a.ldg = ldg;
+    a.dT = (bf16*)dqkv_t; a.ldt = ldt;
     if (!attn_args_ok(a, head_dim) || (lddo & 7) || (ldg & 3) || !lse || !delta) return -1;
     if (head_dim != 128 && rope_pos) return -1;  // the fused inverse RoPE is a head_dim-128 (Llama) epilogue
     if (((uintptr_t)dout & 15) || (((uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 7)) return -1;
+    if (dqkv_t) {  // the transposed copy moves 16-B pieces of 8 tokens
+        if ((long long)ldt < (long long)B * S || (ldt & 7) || ((B * S) & 7) || (ldg & 7) || ((uintptr_t)dqkv_t & 15) ||
+            (((uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 15))
+            return -1;
+    }
     hipStream_t s = (hipStream_t)stream;
     if (head_dim == 64) return causal ? launch_bwd<64, true>(a, s) : launch_bwd<64, false>(a, s);
     return causal ? launch_bwd<128, true>(a, s) : launch_bwd<128, false>(a, s);
+}
+extern "C" int mmu_attn_bwd_rope(const void* q, const void* k, const void* v, int ld, const void* o, int ldo,
+                                 const float* lse, const int* kmask, const void* dout, int lddo, float* delta,
+                                 void* dq, void* dk, void* dv, int ldg, int B, int S, int H, int head_dim, float scale,
+                                 int causal, const int* rope_pos, const void* rope_cos, const void* rope_sin,
+                                 void* stream) {
+    return attn_bwd_impl(q, k, v, ld, o, ldo, lse, kmask, dout, lddo, delta, dq, dk, dv, ldg, B, S, H, head_dim, scale,
+                         causal, rope_pos, rope_cos, rope_sin, nullptr, 0, stream);
+}
+extern "C" int mmu_attn_bwd_rope_t(const void* q, const void* k, const void* v, int ld, const void* o, int ldo,
+                                   const float* lse, const int* kmask, const void* dout, int lddo, float* delta,
+                                   void* dq, void* dk, void* dv, int ldg, int B, int S, int H, int head_dim, float scale,
+                                   int causal, const int* rope_pos, const void* rope_cos, const void* rope_sin,
+                                   void* dqkv_t, int ldt, void* stream) {
+    if (!dqkv_t) return -1;
+    return attn_bwd_impl(q, k, v, ld, o, ldo, lse, kmask, dout, lddo, delta, dq, dk, dv, ldg, B, S, H, head_dim, scale,
+                         causal, rope_pos, rope_cos, rope_sin, dqkv_t, ldt, stream);
 }
 
 #ifdef MMU_ATTN_STAMP

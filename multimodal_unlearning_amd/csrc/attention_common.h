@@ -226,6 +226,10 @@ struct AttnArgs {
     const int* rope_pos;
     const bf16* rope_cos;
     const bf16* rope_sin;
+    // optional transposed copy of the gradients for the q|k|v weight gradient: dT [3][H * D][ldt], element
+    // (part, h * D + d, token) with part 0 = dq, 1 = dk, 2 = dv and token = b * S + s — dqkv^T without a transpose pass
+    bf16* dT;
+    int ldt;
 };
 
 
@@ -268,3 +272,5 @@ int set_lds(K kern, int bytes) {
 int mmu_internal_launch_dkdv4(const void* attn_args, int causal, hipStream_t stream);
 // workgroups of that (persistent) kernel: 0 = one per CU, else a multiple of 8 (tests force several items per workgroup)
 int mmu_internal_set_dkdv4_grid(int n);
+// elementwise.hip: dst[C][R] (row stride ld_dst) = src[R][C] (row stride ld_src)^T
+int mmu_internal_transpose_strided(const void* src, int ld_src, void* dst, int ld_dst, int R, int C, hipStream_t stream);

@@ -491,6 +491,24 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv4_kernel(AttnArgs a, int 
                     for (int i = 0; i < 4; ++i) rows[i] = *(const MMU_LDS u32x4*)(xw + r0 + i * 1024);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(gp + (size_t)i * 8 * a.ldg + h * 64) = rows[i];
+                    if (a.dT) {
+                        // the same image read column-wise (ds_read_b64_tr_b16: a 16-lane group takes 4 keys x 16 d and
+                        // every lane leaves with 4 consecutive keys of ONE d): two reads = 8 keys = 16 B of a row of
+                        // dk^T / dv^T; a store instruction writes 16 such rows x 64 B.
+                        const int g4 = lane_e >> 4, i16 = lane_e & 15;
+                        const int tkey = 8 * g4 + (i16 >> 2);
+                        const int a0 = tkey * 128, a1 = (tkey + 4) * 128;
+                        const int sw0 = ((tkey >> 1) & 3) << 1, sw1 = (((tkey + 4) >> 1) & 3) << 1;
+                        bf16* tp = a.dT + ((size_t)(1 + mat) * a.H * D + out_hh * D + h * 64 + i16) * a.ldt +
+                                   ((size_t)out_b * S + key0 + 8 * g4);
+#pragma unroll
+                        for (int cb = 0; cb < 4; ++cb) {
+                            const int gi = 4 * cb + (i16 & 3);
+                            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((MMU_LDS bf16x4*)(xw + a0 + ((gi ^ sw0) << 3)));
+                            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((MMU_LDS bf16x4*)(xw + a1 + ((gi ^ sw1) << 3)));
+                            *reinterpret_cast<bf16x8*>(tp + (size_t)(16 * cb) * a.ldt) = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                        }
+                    }
                 }
             }
         };

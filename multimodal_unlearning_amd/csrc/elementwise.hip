@@ -658,7 +658,7 @@ __global__ void embed_flush_kernel(float* __restrict__ scratch, int* __restrict_
 // output runs longer (TR * 2 bytes per output row and block; the large transposes are bound by the strided write).
 template <int TR>
 __global__ __launch_bounds__(256) void transpose_kernel(const bf16* __restrict__ src, bf16* __restrict__ dst, int R,
-                                                        int C) {
+                                                        int C, int lds_, int ldd) {  // row strides of src / dst
     constexpr int NP = TR / 2;                                                  // row pairs per tile
     __shared__ __attribute__((aligned(16))) unsigned int tileT[64][NP + 4];    // [source column][row pair]
     const int r0 = blockIdx.y * TR, c0 = blockIdx.x * 64;
@@ -676,8 +676,8 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16* __restrict__
 #pragma unroll
         for (int j = 0; j < 8; ++j) { a[j] = f2bf(0.f); b[j] = f2bf(0.f); }
         if (c < C) {
-            if (r < R) a = *reinterpret_cast<const bf16x8*>(src + (size_t)r * C + c);
-            if (r + 1 < R) b = *reinterpret_cast<const bf16x8*>(src + (size_t)(r + 1) * C + c);
+            if (r < R) a = *reinterpret_cast<const bf16x8*>(src + (size_t)r * lds_ + c);
+            if (r + 1 < R) b = *reinterpret_cast<const bf16x8*>(src + (size_t)(r + 1) * lds_ + c);
         }
         const uint4 au = __builtin_bit_cast(uint4, a), bu = __builtin_bit_cast(uint4, b);
         const unsigned int aw[4] = {au.x, au.y, au.z, au.w}, bw[4] = {bu.x, bu.y, bu.z, bu.w};
@@ -697,7 +697,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16* __restrict__
         const int c = c0 + cl, r = r0 + q * 8;
         if (c < C && r < R) {
             const uint4 v = *reinterpret_cast<const uint4*>(&tileT[cl][(q ^ ((cl >> 3) & 7)) * 4]);
-            *reinterpret_cast<uint4*>(dst + (size_t)c * R + r) = v;
+            *reinterpret_cast<uint4*>(dst + (size_t)c * ldd + r) = v;
         }
     }
 }
@@ -1062,17 +1062,23 @@ extern "C" int mmu_embed_bwd(const long long* ids, const int* slot, const void* 
 }
 
 // dst[C][R] = src[R][C]^T (R, C multiples of 8).  Used to keep W^T resident for the NT dgrad path.
-extern "C" int mmu_transpose_bf16(const void* src, void* dst, int R, int C, void* stream) {
-    if (R <= 0 || C <= 0 || (R & 7) || (C & 7)) return -1;
+// Strided form: src is [R][C] inside rows of ld_src elements, dst [C][R] inside rows of ld_dst (both multiples of 8,
+// 16-B aligned bases): a column block of a wider matrix transposed into a row block of another.
+int mmu_internal_transpose_strided(const void* src, int ld_src, void* dst, int ld_dst, int R, int C, hipStream_t stream) {
+    if (R <= 0 || C <= 0 || (R & 7) || (C & 7) || (ld_src & 7) || (ld_dst & 7) || ld_src < C || ld_dst < R) return -1;
+    if ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) return -1;
     if (R >= 4096) {  // long output rows: 256-row tiles (512-B output runs)
-        hipLaunchKernelGGL(transpose_kernel<256>, dim3((C + 63) / 64, (R + 255) / 256), dim3(256), 0, (hipStream_t)stream,
-                           (const bf16*)src, (bf16*)dst, R, C);
+        hipLaunchKernelGGL(transpose_kernel<256>, dim3((C + 63) / 64, (R + 255) / 256), dim3(256), 0, stream,
+                           (const bf16*)src, (bf16*)dst, R, C, ld_src, ld_dst);
     } else {
-        hipLaunchKernelGGL(transpose_kernel<64>, dim3((C + 63) / 64, (R + 63) / 64), dim3(256), 0, (hipStream_t)stream,
-                           (const bf16*)src, (bf16*)dst, R, C);
+        hipLaunchKernelGGL(transpose_kernel<64>, dim3((C + 63) / 64, (R + 63) / 64), dim3(256), 0, stream,
+                           (const bf16*)src, (bf16*)dst, R, C, ld_src, ld_dst);
     }
     MMU_CHECK_LAUNCH();
     return 0;
+}
+extern "C" int mmu_transpose_bf16(const void* src, void* dst, int R, int C, void* stream) {
+    return mmu_internal_transpose_strided(src, C, dst, R, R, C, (hipStream_t)stream);
 }
 
 // act^T [I][M] = swiglu(gate|up [M][2I])^T

@@ -36,6 +36,8 @@ SIGNATURES = {
                      _vp],
     "mmu_attn_bwd_rope": [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i,
                           _vp, _vp, _vp, _vp],
+    "mmu_attn_bwd_rope_t": [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i,
+                            _vp, _vp, _vp, _vp, _i, _vp],
     "mmu_attn_set_dkdv_variant": [_i],
     "mmu_rmsnorm_fwd": [_vp, _vp, _vp, _vp, _i, _i, _f, _vp],
     "mmu_rmsnorm_bwd_nparts": [_i],
@@ -247,17 +249,23 @@ def attn_fwd(q, k, v, out, lse, kmask, B, S, H, head_dim, scale, causal):
     return out
 
 
-def attn_bwd(q, k, v, o, lse, kmask, dout, delta, dq, dk, dv, B, S, H, head_dim, scale, causal, rope=None):
+def attn_bwd(q, k, v, o, lse, kmask, dout, delta, dq, dk, dv, B, S, H, head_dim, scale, causal, rope=None, dqkv_t=None):
     """rope = (pos_ids int32 [B*S], cos_t, sin_t [n_pos,64]): fuse the inverse RoPE rotation into the dq / dk stores.
-    delta: fp32 workspace of 2 * B * H * S floats (delta, then lse * log2 e)."""
+    delta: fp32 workspace of 2 * B * H * S floats (delta, then lse * log2 e).
+    dqkv_t (bf16 [3 * H * head_dim, B * S], optional): also leave [dq | dk | dv]^T, the A operand of the q|k|v weight
+    gradient, without a separate transpose of the packed gradient."""
     _bf16c(q, k, v, o, dout, dq, dk, dv)
     assert dq.stride(0) == dk.stride(0) == dv.stride(0)
     assert delta.dtype == torch.float32 and delta.is_contiguous() and delta.numel() >= 2 * B * S * H
     pos, ct, st = rope if rope is not None else (None, None, None)
-    rc = load().mmu_attn_bwd_rope(_p(q), _p(k), _p(v), q.stride(0), _p(o), o.stride(0), _p(lse), _p(kmask), _p(dout),
-                                  dout.stride(0), _p(delta), _p(dq), _p(dk), _p(dv), dq.stride(0), B, S, H, head_dim,
-                                  float(scale), int(causal), _p(pos), _p(ct), _p(st), _stream())
-    _check(rc, "mmu_attn_bwd_rope")
+    args = (_p(q), _p(k), _p(v), q.stride(0), _p(o), o.stride(0), _p(lse), _p(kmask), _p(dout), dout.stride(0), _p(delta),
+            _p(dq), _p(dk), _p(dv), dq.stride(0), B, S, H, head_dim, float(scale), int(causal), _p(pos), _p(ct), _p(st))
+    if dqkv_t is None:
+        _check(load().mmu_attn_bwd_rope(*args, _stream()), "mmu_attn_bwd_rope")
+        return
+    _bf16c(dqkv_t)
+    assert dqkv_t.dim() == 2 and dqkv_t.shape[0] == 3 * H * head_dim and dqkv_t.shape[1] == B * S and dqkv_t.stride(1) == 1
+    _check(load().mmu_attn_bwd_rope_t(*args, _p(dqkv_t), dqkv_t.stride(0), _stream()), "mmu_attn_bwd_rope_t")
 
 
 DKDV_DEFAULT = 4

@@ -205,6 +205,7 @@ class LlavaHIP(nn.Module):
         self.transposed_wgrad = True
         self.transposed_wgrad_min_m = 1024
         self.fuse_rope = os.environ.get("MMU_NO_ROPE_FUSION", "0") != "1"  # A/B switch
+        self.fuse_dqkv_t = os.environ.get("MMU_NO_DQKV_T", "0") != "1"     # A/B switch: dqkv^T written by attention backward
         # keep act^T of every layer from forward to backward (+ layers*M*I*2 B, 23 GB at 7B / 30 sequences) instead of
         # recomputing it from gate|up in backward; the owner of the step turns it on when HBM allows (bench.py does)
         self.keep_act_t = False
@@ -888,15 +889,20 @@ class LlavaHIP(nn.Module):
             da = dh  # reuse the buffer of the (now consumed) upstream gradient
             self._lin_bwd(p + "o.weight", dh2, a, da)
             dqkv = torch.empty(M, 3 * dt, device=dev, dtype=BF)
+            # the backward kernels also leave dqkv^T for the q|k|v weight gradient (the persistent dK/dV kernel writes its
+            # two thirds from the staging image it already has; only valid while RoPE is fused into the same stores)
+            dqkvT = (torch.empty(3 * dt, M, device=dev, dtype=BF)
+                     if (use_t and self.fuse_rope and self.fuse_dqkv_t and M % 8 == 0) else None)
             hip.attn_bwd(qkv[:, :dt], qkv[:, dt:2 * dt], qkv[:, 2 * dt:], a, lse, saved["kmask"], da, delta,
                          dqkv[:, :dt], dqkv[:, dt:2 * dt], dqkv[:, 2 * dt:], B, S, H, D, scale, True,
-                         rope=(saved["pos"], self._cos, self._sin) if self.fuse_rope else None)
+                         rope=(saved["pos"], self._cos, self._sin) if self.fuse_rope else None, dqkv_t=dqkvT)
             if not self.fuse_rope:
                 hip.rope(dqkv, saved["pos"], self._cos, self._sin, H, H, D, dt, inverse=True)
             del qkv, a
             if use_t:
                 hip.rmsnorm_apply_t(hin, w[p + "input_norm.weight"], rstd1, yT)
-                self._wgrad_t(dqkv, None, yT, p + "qkv.weight")
+                self._wgrad_t(dqkv, dqkvT, yT, p + "qkv.weight")
+                del dqkvT
                 self._dgrad(dqkv, p + "qkv.weight", dy)
             else:
                 hip.rmsnorm_fwd(hin, w[p + "input_norm.weight"], y, None, t.rms_norm_eps)

@@ -239,6 +239,43 @@ def test_attn_bwd(dev, B, H, S, causal, pad, D, variant):
         assert _relerr(got, exp) < 1.5e-2, (name, _relerr(got, exp))
 
 
+@pytest.mark.parametrize("B,H,S,D,causal,use_rope", [(2, 4, 96, 128, True, True), (1, 8, 1088, 128, True, True),
+                                                    (3, 8, 288, 128, True, False), (2, 3, 200, 128, True, True),
+                                                    (2, 8, 416, 128, False, False), (2, 3, 72, 64, False, False)])
+@pytest.mark.parametrize("variant", [(8, 0), (4, 0), (4, 8)], ids=["w8", "w4", "w4-grid8"])
+def test_attn_bwd_transposed_copy(dev, B, H, S, D, causal, use_rope, variant):
+    """mmu_attn_bwd_rope_t: dqkv_t == dqkv^T bit for bit (with and without the fused inverse RoPE), and dqkv itself is
+    what the call without the transposed copy writes — whichever kernel or strided transpose produced each third."""
+    hip.attn_set_dkdv_variant(*variant)
+    g = torch.Generator().manual_seed(S + H)
+    HD = H * D
+    M = B * S
+    qkv = (torch.randn(M, 3 * HD, generator=g) * 0.5).to(dev).to(BF)
+    do = torch.randn(M, HD, generator=g).to(dev).to(BF)
+    o = torch.empty(M, HD, device=dev, dtype=BF)
+    lse = torch.empty(B, H, S, device=dev, dtype=torch.float32)
+    sc = 1 / math.sqrt(D)
+    hip.attn_fwd(qkv[:, :HD], qkv[:, HD:2 * HD], qkv[:, 2 * HD:], o, lse, None, B, S, H, D, sc, causal)
+    rope = None
+    if use_rope:
+        pos = torch.arange(S, dtype=torch.int32, device=dev).repeat(B)
+        cos_t = torch.empty(S, D // 2, device=dev, dtype=BF)
+        sin_t = torch.empty(S, D // 2, device=dev, dtype=BF)
+        hip.rope_table(cos_t, sin_t, S, D, 10000.0)
+        rope = (pos, cos_t, sin_t)
+    delta = torch.empty(2, B, H, S, device=dev, dtype=torch.float32)
+    d_ref = torch.full((M, 3 * HD), 7.0, device=dev, dtype=BF)
+    hip.attn_bwd(qkv[:, :HD], qkv[:, HD:2 * HD], qkv[:, 2 * HD:], o, lse, None, do, delta, d_ref[:, :HD], d_ref[:, HD:2 * HD],
+                 d_ref[:, 2 * HD:], B, S, H, D, sc, causal, rope=rope)
+    d1 = torch.full((M, 3 * HD), 5.0, device=dev, dtype=BF)
+    dT = torch.full((3 * HD, M), 3.0, device=dev, dtype=BF)
+    hip.attn_bwd(qkv[:, :HD], qkv[:, HD:2 * HD], qkv[:, 2 * HD:], o, lse, None, do, delta, d1[:, :HD], d1[:, HD:2 * HD],
+                 d1[:, 2 * HD:], B, S, H, D, sc, causal, rope=rope, dqkv_t=dT)
+    torch.cuda.synchronize()
+    assert torch.equal(d1, d_ref)
+    assert torch.equal(dT, d1.t().contiguous())
+
+
 # ------------------------------------------------------------------------------------------------ norms
 @pytest.mark.parametrize("M,d", [(5, 64), (33, 1024), (130, 4096), (7, 5120)])
 def test_rmsnorm(dev, M, d):
