@@ -401,6 +401,33 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
             }
         }
     }
+    if constexpr (D == 128) {
+        // Sequences that are a multiple of 32 long (a wave's 32 query rows exist or none does) store through LDS: whole
+        // 128-B lines row-major and, on request, the transposed copy for the q weight gradient (store_tile32x128_via_lds).
+        // The K / V tile buffers are free once every wave has left the key loop.
+        if (a.S % 32 == 0) {
+            __syncthreads();
+            if (q0 < S) {
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[dt][r] *= a.scale;
+                const bf16* cr = nullptr;
+                const bf16* sr = nullptr;
+                if (a.rope_pos) {
+                    const int pos = a.rope_pos[rowbase + qrow];
+                    cr = a.rope_cos + (size_t)pos * 64;
+                    sr = a.rope_sin + (size_t)pos * 64;
+                }
+                u32x2 w[4][4];
+                grad_words(acc, hl, cr, sr, w);
+                store_tile32x128_via_lds((MMU_LDS char*)smem + wave * 4096, w, lane,
+                                         a.dq + (rowbase + q0) * a.ldg + hh * D, a.ldg,
+                                         a.dT ? a.dT + (size_t)(hh * D) * a.ldt + rowbase + q0 : nullptr, a.ldt);
+            }
+            return;
+        }
+    }
     if (qvalid) {
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt)
@@ -756,7 +783,8 @@ int launch_bwd(const AttnArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((attn_bwd_dq_kernel<D, CAUSAL>), dim3(((a.S + 127) / 128) * a.H * a.B), dim3(256), LDS_DQ, s, a);
     MMU_CHECK_LAUNCH();
     if (a.dT) {
-        int e = transpose_part(0, a.dq);
+        const bool q_t_done = D == 128 && a.S % 32 == 0;  // the dQ kernel's LDS-staged epilogue wrote dq^T
+        int e = q_t_done ? 0 : transpose_part(0, a.dq);
         if (!e && !kv_t_done) e = transpose_part(1, a.dk);
         if (!e && !kv_t_done) e = transpose_part(2, a.dv);
         if (e) return e;

@@ -189,6 +189,91 @@ __device__ __forceinline__ void store_grad_row(bf16* dst, const f32x16 (&acc)[4]
 }
 
 
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// A 32-row x 128-column bf16 tile held "row on the lane" — lane (row = lane & 31, hl = lane >> 5) holds w[dt][g] = the
+// four columns 32 dt + 8 g + 4 hl .. + 3 of its row, the layout of the dQ^T / dK^T / dV^T accumulators — written out
+// through a 4-KiB LDS area private to the wave, one 64-column half at a time:
+//  * row-major: 8 ds_write_b64 in, 4 ds_read_b128 out with 8 lanes per row, so a store instruction writes 8 whole
+//    128-B lines (storing straight from the registers touches 32 rows x 32 B per instruction: ~440 cycles of issue);
+//  * transposed (t0 != nullptr): the same image read column-wise with ds_read_b64_tr_b16 (a 16-lane group takes
+//    4 rows x 16 columns, every lane leaves with 4 consecutive rows of ONE column); two reads = 8 rows = 16 B of a row of
+//    the transposed matrix, a store instruction writes 16 such rows x 64 B.
+// Image: [row][16 granules of 8 B], granule ^= ((row >> 1) & 3) << 1.  g0 -> (first row, first column) of the row-major
+// destination (row stride ldg), t0 -> (first column, first row) of the transposed one (row stride ldt).  All 32 rows
+// are written, EXEC must be full (ds_read_b64_tr_b16), and nothing but this wave may touch xw[0, 4096).
+__device__ __forceinline__ void store_tile32x128_via_lds(MMU_LDS char* xw, const u32x2 (&w)[4][4], int lane, bf16* g0,
+                                                         int ldg, bf16* t0, int ldt) {
+    const int kr = lane & 31, rr = lane >> 3, hl = lane >> 5;
+    const int w0 = kr * 128 + ((hl ^ (((kr >> 1) & 3) << 1)) << 3);
+    const int r0 = rr * 128 + (((lane & 7) ^ ((rr >> 1) & 3)) << 4);
+    bf16* gp = g0 + (size_t)rr * ldg + (lane & 7) * 8;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int dtl = 0; dtl < 2; ++dtl)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) *(MMU_LDS u32x2*)(xw + (w0 ^ (g << 4)) + dtl * 64) = w[2 * h + dtl][g];
+        u32x4 rows[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rows[i] = *(const MMU_LDS u32x4*)(xw + r0 + i * 1024);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(gp + (size_t)i * 8 * ldg + h * 64) = rows[i];
+        if (t0) {
+            const int g4 = lane >> 4, i16 = lane & 15;
+            const int trow = 8 * g4 + (i16 >> 2);
+            const int a0 = trow * 128, a1 = (trow + 4) * 128;
+            const int sw0 = ((trow >> 1) & 3) << 1, sw1 = (((trow + 4) >> 1) & 3) << 1;
+            bf16* tp = t0 + (size_t)(h * 64 + i16) * ldt + 8 * g4;
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                const int gi = 4 * cb + (i16 & 3);
+                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((MMU_LDS bf16x4*)(xw + a0 + ((gi ^ sw0) << 3)));
+                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((MMU_LDS bf16x4*)(xw + a1 + ((gi ^ sw1) << 3)));
+                *reinterpret_cast<bf16x8*>(tp + (size_t)(16 * cb) * ldt) = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+        }
+    }
+}
+
+// The bf16 words of a gradient tile for store_tile32x128_via_lds: acc[dt][4 g + j] <-> column 32 dt + 8 g + 4 hl + j,
+// optionally with the transpose rotation of RoPE on the (d, d + 64) pairs = (dt, dt + 2) (same arithmetic as
+// rope_kernel(inverse=1) on the bf16-rounded gradient; cos_row / sin_row: the row's 64 table entries, or nullptr).
+__device__ __forceinline__ void grad_words(const f32x16 (&acc)[4], int hl, const bf16* cos_row, const bf16* sin_row,
+                                           u32x2 (&w)[4][4]) {
+    if (cos_row) {
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d = dt * 32 + 8 * g + 4 * hl;  // < 64
+                const bf16x4 c4 = *reinterpret_cast<const bf16x4*>(cos_row + d);
+                const bf16x4 s4 = *reinterpret_cast<const bf16x4*>(sin_row + d);
+                bf16x4 t, u;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float x = round_bf16(acc[dt][4 * g + j]), y = round_bf16(acc[dt + 2][4 * g + j]);
+                    const float cf = bf2f(c4[j]), sf = bf2f(s4[j]);
+                    t[j] = f2bf(round_bf16(x * cf) + round_bf16(y * sf));
+                    u[j] = f2bf(round_bf16(y * cf) + round_bf16(-x * sf));
+                }
+                w[dt][g] = __builtin_bit_cast(u32x2, t);
+                w[dt + 2][g] = __builtin_bit_cast(u32x2, u);
+            }
+    } else {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 t;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) t[j] = f2bf(acc[dt][4 * g + j]);
+                w[dt][g] = __builtin_bit_cast(u32x2, t);
+            }
+    }
+}
+
 // Plain store of a gradient row fragment for any head_dim (acc[dt][4g+j] <-> d = dt*32 + 8g + 4*hl + j).
 template <int NDT>
 __device__ __forceinline__ void store_grad_row_plain(bf16* dst, const f32x16 (&acc)[NDT], int hl) {

@@ -400,56 +400,21 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv4_kernel(AttnArgs a, int 
         // as rope_kernel(inverse=1) on the bf16-rounded gradient), bf16; lane (key, hl) holds d = 32 dt + 8 g + 4 hl + j.
         STAMP(t_e0);
         const int out_key = key, out_hh = hh, out_b = b;  // the row index is re-formed below (a 64-bit VGPR pair less to keep)
-        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
         u32x2 wk[NDT][4], wv[NDT][4];  // bf16x4 words of dK / dV per (dt, g)
         {
 #pragma unroll
             for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) dk[dt][r] *= a.scale;
+            const bf16* cr = nullptr;
+            const bf16* sr = nullptr;
             if (a.rope_pos) {
                 const int pos = out_key < S ? a.rope_pos[(size_t)out_b * S + out_key] : 0;
-                const bf16* cr = a.rope_cos + (size_t)pos * 64;
-                const bf16* sr = a.rope_sin + (size_t)pos * 64;
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int d = dt * 32 + 8 * g + 4 * hl;  // < 64
-                        const bf16x4 c4 = *reinterpret_cast<const bf16x4*>(cr + d);
-                        const bf16x4 s4 = *reinterpret_cast<const bf16x4*>(sr + d);
-                        bf16x4 t, u;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float x = round_bf16(dk[dt][4 * g + j]), y = round_bf16(dk[dt + 2][4 * g + j]);
-                            const float cf = bf2f(c4[j]), sf = bf2f(s4[j]);
-                            t[j] = f2bf(round_bf16(x * cf) + round_bf16(y * sf));
-                            u[j] = f2bf(round_bf16(y * cf) + round_bf16(-x * sf));
-                        }
-                        wk[dt][g] = __builtin_bit_cast(u32x2, t);
-                        wk[dt + 2][g] = __builtin_bit_cast(u32x2, u);
-                    }
-            } else {
-#pragma unroll
-                for (int dt = 0; dt < NDT; ++dt)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        bf16x4 t;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) t[j] = f2bf(dk[dt][4 * g + j]);
-                        wk[dt][g] = __builtin_bit_cast(u32x2, t);
-                    }
+                cr = a.rope_cos + (size_t)pos * 64;
+                sr = a.rope_sin + (size_t)pos * 64;
             }
-#pragma unroll
-            for (int dt = 0; dt < NDT; ++dt)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    bf16x4 t;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) t[j] = f2bf(dv[dt][4 * g + j]);
-                    wv[dt][g] = __builtin_bit_cast(u32x2, t);
-                }
+            grad_words(dk, hl, cr, sr, wk);
+            grad_words(dv, hl, nullptr, nullptr, wv);
         }
         STAMP(t_e1);
         // the next item's K / V (and key mask) are requested BEFORE this item's stores go out; the wait in front of the
@@ -472,45 +437,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv4_kernel(AttnArgs a, int 
             MMU_LDS char* xw = (MMU_LDS char*)smem + XLDS + wave * 4096;
             int lane_e = lane;
             asm volatile("" : "+v"(lane_e));  // keeps the address arithmetic below here (hoisted to the item's top it was spilled)
-            const int kr = lane_e & 31, rr = lane_e >> 3, hl_e = lane_e >> 5;
-            const int w0 = kr * 128 + ((hl_e ^ (((kr >> 1) & 3) << 1)) << 3);
-            const int r0 = rr * 128 + (((lane_e & 7) ^ ((rr >> 1) & 3)) << 4);
-            const size_t out_off = ((size_t)out_b * S + key0 + rr) * a.ldg + out_hh * D + (lane_e & 7) * 8;
-#pragma unroll
-            for (int mat = 0; mat < 2; ++mat) {
-                bf16* gp = (mat ? a.dv : a.dk) + out_off;
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-#pragma unroll
-                    for (int dtl = 0; dtl < 2; ++dtl)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g)
-                            *(MMU_LDS u32x2*)(xw + (w0 ^ (g << 4)) + dtl * 64) = mat ? wv[2 * h + dtl][g] : wk[2 * h + dtl][g];
-                    u32x4 rows[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) rows[i] = *(const MMU_LDS u32x4*)(xw + r0 + i * 1024);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(gp + (size_t)i * 8 * a.ldg + h * 64) = rows[i];
-                    if (a.dT) {
-                        // the same image read column-wise (ds_read_b64_tr_b16: a 16-lane group takes 4 keys x 16 d and
-                        // every lane leaves with 4 consecutive keys of ONE d): two reads = 8 keys = 16 B of a row of
-                        // dk^T / dv^T; a store instruction writes 16 such rows x 64 B.
-                        const int g4 = lane_e >> 4, i16 = lane_e & 15;
-                        const int tkey = 8 * g4 + (i16 >> 2);
-                        const int a0 = tkey * 128, a1 = (tkey + 4) * 128;
-                        const int sw0 = ((tkey >> 1) & 3) << 1, sw1 = (((tkey + 4) >> 1) & 3) << 1;
-                        bf16* tp = a.dT + ((size_t)(1 + mat) * a.H * D + out_hh * D + h * 64 + i16) * a.ldt +
-                                   ((size_t)out_b * S + key0 + 8 * g4);
-#pragma unroll
-                        for (int cb = 0; cb < 4; ++cb) {
-                            const int gi = 4 * cb + (i16 & 3);
-                            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((MMU_LDS bf16x4*)(xw + a0 + ((gi ^ sw0) << 3)));
-                            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((MMU_LDS bf16x4*)(xw + a1 + ((gi ^ sw1) << 3)));
-                            *reinterpret_cast<bf16x8*>(tp + (size_t)(16 * cb) * a.ldt) = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                        }
-                    }
-                }
-            }
+            const size_t row0 = (size_t)out_b * S + key0;
+            const size_t g_off = row0 * a.ldg + out_hh * D;
+            bf16* t_k = a.dT ? a.dT + ((size_t)a.H * D + out_hh * D) * a.ldt + row0 : nullptr;
+            bf16* t_v = a.dT ? t_k + (size_t)a.H * D * a.ldt : nullptr;
+            store_tile32x128_via_lds(xw, wk, lane_e, a.dk + g_off, a.ldg, t_k, a.ldt);
+            store_tile32x128_via_lds(xw, wv, lane_e, a.dv + g_off, a.ldg, t_v, a.ldt);
         };
         const bool do_stores = !((DKDV4_EXP & 8) && a.scale != 12345.f);  // (the experiment keeps the stores reachable: no DCE)
         // the launcher only takes this kernel for S % 32 == 0: a wave's 32 keys exist or none of them does
