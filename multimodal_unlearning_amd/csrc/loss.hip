@@ -36,6 +36,42 @@ __device__ __forceinline__ void wave_merge(OnlineLse& o) {
     }
 }
 
+// Online log-sum-exp that also carries w = sum_i e^(x_i - m) y_i, so that sum_i softmax(x)_i y_i = w / s needs no
+// second walk (and no second exp) over the row once the log-sum-exp is known.
+struct OnlineLseW {
+    float m, s, w;
+    __device__ __forceinline__ void init() { m = -INFINITY; s = 0.f; w = 0.f; }
+    __device__ __forceinline__ void merge(float m2, float s2, float w2) {
+        const float mn = fmaxf(m, m2);
+        if (mn == -INFINITY) return;
+        const float a = __expf(m - mn), b = __expf(m2 - mn);
+        s = s * a + s2 * b;
+        w = w * a + w2 * b;
+        m = mn;
+    }
+};
+__device__ __forceinline__ void wave_merge(OnlineLseW& o) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float m2 = __shfl_xor(o.m, off, 64), s2 = __shfl_xor(o.s, off, 64), w2 = __shfl_xor(o.w, off, 64);
+        o.merge(m2, s2, w2);
+    }
+}
+// x: the logits the softmax is taken over, y: the per-element factor (8 of each)
+__device__ __forceinline__ void lse_chunk_w(OnlineLseW& o, const bf16x8& x, const float (&y)[8]) {
+    float mx = bf2f(x[0]);
+#pragma unroll
+    for (int j = 1; j < 8; ++j) mx = fmaxf(mx, bf2f(x[j]));
+    float sm = 0.f, wm = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float e = __expf(bf2f(x[j]) - mx);
+        sm += e;
+        wm += e * y[j];
+    }
+    o.merge(mx, sm, wm);
+}
+
 // block-wide logsumexp for a row of V bf16 logits (V % 8 == 0). scratch: 8 floats.
 __device__ __forceinline__ float block_lse(const bf16* __restrict__ row, int V, float* scratch) {
     OnlineLse o;
@@ -259,6 +295,7 @@ __global__ __launch_bounds__(512, 4) void rowloss_fwd_regs_kernel(const bf16* __
     constexpr bool HAS_T = MODE != 3;
     constexpr int mode = MODE;  // compile-time: the per-element body stays small enough to unroll 8 x 8 times
     __shared__ float scratch[16];
+    __shared__ float wscratch[40];
     const int row = blockIdx.x;
     const bf16* sr = slog + (size_t)row * ldv;
     const bf16* tr = HAS_T ? tlog + (size_t)row * ldv : nullptr;
@@ -288,6 +325,59 @@ __global__ __launch_bounds__(512, 4) void rowloss_fwd_regs_kernel(const bf16* __
         for (int i = 1; i < 8; ++i) t.merge(scratch[i], scratch[8 + i]);
         return t.m + __logf(t.s);
     };
+    if constexpr (MODE == 0 || MODE == 1 || MODE == 3) {
+        // The three expectation-type rows in ONE walk over the registers and one exp per logit: with x the logits of the
+        // distribution the expectation is taken under (teacher for mode 0, student for modes 1 and 3) and
+        // y = x - other (modes 0, 1) or y = x (mode 3),  row value = E_softmax(x)[y] - lse(x) + lse(other)  (mode 3:
+        // E[x] - lse(x)); E[y] = w / s from the weighted online log-sum-exp.  (The streaming kernel keeps the three-walk
+        // form p * (lp - lp'); the two agree to fp32 rounding of the row sums.)
+        OnlineLseW ow;
+        OnlineLse oo;
+        ow.init();
+        oo.init();
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            if (threadIdx.x + i * 512 < nch) {
+                const bf16x8& x = (MODE == 0) ? tv[i] : sv[i];
+                float y[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    y[j] = (MODE == 3) ? bf2f(sv[i][j]) : (MODE == 0 ? bf2f(tv[i][j]) - bf2f(sv[i][j]) : bf2f(sv[i][j]) - bf2f(tv[i][j]));
+                lse_chunk_w(ow, x, y);
+                if (MODE != 3) lse_chunk(oo, MODE == 0 ? sv[i] : tv[i]);
+            }
+        }
+        wave_merge(ow);
+        if (MODE != 3) wave_merge(oo);
+        __syncthreads();
+        if (l == 0) {
+            wscratch[w] = ow.m;
+            wscratch[8 + w] = ow.s;
+            wscratch[16 + w] = ow.w;
+            wscratch[24 + w] = oo.m;
+            wscratch[32 + w] = oo.s;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            OnlineLseW tw;
+            OnlineLse to;
+            tw.m = wscratch[0]; tw.s = wscratch[8]; tw.w = wscratch[16];
+            to.m = wscratch[24]; to.s = wscratch[32];
+#pragma unroll
+            for (int i = 1; i < 8; ++i) {
+                tw.merge(wscratch[i], wscratch[8 + i], wscratch[16 + i]);
+                to.merge(wscratch[24 + i], wscratch[32 + i]);
+            }
+            const float lx = tw.m + __logf(tw.s);
+            const float lo = (MODE == 3) ? 0.f : to.m + __logf(to.s);
+            float* st = stats + (size_t)row * 4;
+            st[0] = (MODE == 0) ? lo : lx;   // lse of the student row
+            st[1] = (MODE == 0) ? lx : lo;   // lse of the teacher row (0 when unused)
+            st[2] = tw.w / tw.s - lx + lo;
+            st[3] = 0.f;
+        }
+        return;
+    }
     OnlineLse os, ot;
     os.init();
     ot.init();
@@ -295,6 +385,7 @@ __global__ __launch_bounds__(512, 4) void rowloss_fwd_regs_kernel(const bf16* __
     for (int i = 0; i < NC; ++i)
         if (threadIdx.x + i * 512 < nch) lse_chunk(os, sv[i]);
     const float ls = finish(os);
+
     float lt = 0.f;
     if (HAS_T) {
 #pragma unroll
