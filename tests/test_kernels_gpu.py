@@ -276,6 +276,43 @@ def test_attn_bwd_transposed_copy(dev, B, H, S, D, causal, use_rope, variant):
     assert torch.equal(dT, d1.t().contiguous())
 
 
+def test_attn_bwd_step_size_kernels_agree(dev):
+    """The headline step's attention shape (30 sequences x 32 heads x 1088 x 128, causal, fused inverse RoPE): the
+    persistent four-wave dK/dV kernel (34 items and ~300 ring steps per workgroup, ring running across item seams) and
+    the eight-wave kernel give the same gradients to bf16 rounding of different summation orders, and dqkv^T is the
+    transpose of dqkv bit for bit.  (No oracle at this size: the small shapes above pin both kernels to the fp32
+    reference.)"""
+    B, H, S, D = 30, 32, 1088, 128
+    HD, M = H * D, B * S
+    g = torch.Generator(device=dev).manual_seed(5)
+    qkv = (torch.randn(M, 3 * HD, device=dev, generator=g) * 0.5).to(BF)
+    do = torch.randn(M, HD, device=dev, generator=g).to(BF)
+    o = torch.empty(M, HD, device=dev, dtype=BF)
+    lse = torch.empty(B, H, S, device=dev, dtype=torch.float32)
+    sc = 1 / math.sqrt(D)
+    hip.attn_fwd(qkv[:, :HD], qkv[:, HD:2 * HD], qkv[:, 2 * HD:], o, lse, None, B, S, H, D, sc, True)
+    pos = torch.arange(S, dtype=torch.int32, device=dev).repeat(B)
+    cos_t = torch.empty(S, D // 2, device=dev, dtype=BF)
+    sin_t = torch.empty(S, D // 2, device=dev, dtype=BF)
+    hip.rope_table(cos_t, sin_t, S, D, 10000.0)
+    delta = torch.empty(2, B, H, S, device=dev, dtype=torch.float32)
+    outs = {}
+    for v in (8, 4):
+        hip.attn_set_dkdv_variant(v)
+        d = torch.empty(M, 3 * HD, device=dev, dtype=BF)
+        dT = torch.empty(3 * HD, M, device=dev, dtype=BF)
+        hip.attn_bwd(qkv[:, :HD], qkv[:, HD:2 * HD], qkv[:, 2 * HD:], o, lse, None, do, delta, d[:, :HD], d[:, HD:2 * HD],
+                     d[:, 2 * HD:], B, S, H, D, sc, True, rope=(pos, cos_t, sin_t), dqkv_t=dT)
+        torch.cuda.synchronize()
+        assert torch.isfinite(d.float()).all()
+        for part in range(3):  # piecewise: a full .t().contiguous() of 800 MB is not needed
+            assert torch.equal(dT[part * HD:(part + 1) * HD], d[:, part * HD:(part + 1) * HD].t().contiguous()), (v, part)
+        outs[v] = d
+        del dT
+    assert torch.equal(outs[4][:, :HD], outs[8][:, :HD])  # dq comes from the same kernel either way
+    assert _relerr(outs[4][:, HD:], outs[8][:, HD:]) < 2e-3
+
+
 # ------------------------------------------------------------------------------------------------ norms
 @pytest.mark.parametrize("M,d", [(5, 64), (33, 1024), (130, 4096), (7, 5120)])
 def test_rmsnorm(dev, M, d):
