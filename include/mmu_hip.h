@@ -83,8 +83,9 @@ int mmu_attn_bwd_rope(const void* q, const void* k, const void* v, int ld, const
 
 /* mmu_attn_bwd_rope that additionally leaves [dq | dk | dv]^T = dqkv_t [3 * H * head_dim][ldt] (ldt >= B * S, a multiple of
  * 8; B * S a multiple of 8; dq / dk / dv 16-B aligned with ldg a multiple of 8): the A operand of the q|k|v weight
- * gradient (mm/trainer.py backward of q_proj / k_proj / v_proj) without a transpose pass.  The persistent dK/dV kernel
- * writes its two thirds itself; the rest is a strided transpose of the finished block. */
+ * gradient (mm/trainer.py backward of q_proj / k_proj / v_proj) without a transpose pass.  For head_dim 128 and S a
+ * multiple of 8 the dQ and the persistent dK/dV kernels write their parts themselves; otherwise (and for the eight-wave
+ * dK/dV kernel) the part is a strided transpose of the finished block. */
 int mmu_attn_bwd_rope_t(const void* q, const void* k, const void* v, int ld, const void* o, int ldo, const float* lse,
                         const int* kmask, const void* dout, int lddo, float* delta, void* dq, void* dk, void* dv, int ldg,
                         int B, int S, int H, int head_dim, float scale, int causal, const int* rope_pos,

@@ -402,31 +402,30 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
         }
     }
     if constexpr (D == 128) {
-        // Sequences that are a multiple of 32 long (a wave's 32 query rows exist or none does) store through LDS: whole
-        // 128-B lines row-major and, on request, the transposed copy for the q weight gradient (store_tile32x128_via_lds).
-        // The K / V tile buffers are free once every wave has left the key loop.
-        if (a.S % 32 == 0) {
-            __syncthreads();
-            if (q0 < S) {
+        // The gradient tile leaves through LDS: whole 128-B lines row-major and, on request, the transposed copy for the q
+        // weight gradient (store_tile32x128_via_lds).  The K / V tile buffers are free once every wave has left the key
+        // loop.  a.dT is only passed for sequence lengths that are multiples of 8 (launch_bwd).
+        __syncthreads();
+        if (q0 < S) {
 #pragma unroll
-                for (int dt = 0; dt < NDT; ++dt)
+            for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[dt][r] *= a.scale;
-                const bf16* cr = nullptr;
-                const bf16* sr = nullptr;
-                if (a.rope_pos) {
-                    const int pos = a.rope_pos[rowbase + qrow];
-                    cr = a.rope_cos + (size_t)pos * 64;
-                    sr = a.rope_sin + (size_t)pos * 64;
-                }
-                u32x2 w[4][4];
-                grad_words(acc, hl, cr, sr, w);
-                store_tile32x128_via_lds((MMU_LDS char*)smem + wave * 4096, w, lane,
-                                         a.dq + (rowbase + q0) * a.ldg + hh * D, a.ldg,
-                                         a.dT ? a.dT + (size_t)(hh * D) * a.ldt + rowbase + q0 : nullptr, a.ldt);
+                for (int r = 0; r < 16; ++r) acc[dt][r] *= a.scale;
+            const bf16* cr = nullptr;
+            const bf16* sr = nullptr;
+            if (a.rope_pos) {
+                const int pos = a.rope_pos[rowbase + (qvalid ? qrow : S - 1)];
+                cr = a.rope_cos + (size_t)pos * 64;
+                sr = a.rope_sin + (size_t)pos * 64;
             }
-            return;
+            u32x2 w[4][4];
+            grad_words(acc, hl, cr, sr, w);
+            store_tile32x128_via_lds<false>((MMU_LDS char*)smem + wave * 4096, w, lane,
+                                            a.dq + (rowbase + q0) * a.ldg + hh * D, a.ldg,
+                                            a.dT ? a.dT + (size_t)(hh * D) * a.ldt + rowbase + q0 : nullptr, a.ldt,
+                                            min(32, S - q0));
         }
+        return;
     }
     if (qvalid) {
 #pragma unroll
@@ -758,35 +757,37 @@ int launch_bwd(const AttnArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((attn_delta_kernel<D>), dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, a.o, a.ldo, a.dout,
                        a.lddo, const_cast<float*>(a.delta), a.lse, a.B, a.S, a.H);
     MMU_CHECK_LAUNCH();
-    // Transposed gradient copy (a.dT): the four-wave dK/dV kernel writes dk^T / dv^T itself; every other part goes through
-    // a strided transpose of the finished row-major block (same bytes as the caller's own transpose pass would move).
+    // Transposed gradient copy (a.dT): the head_dim-128 dQ kernel and the four-wave dK/dV kernel write their parts
+    // themselves when the sequence length is a multiple of 8 (the copy moves 16-B groups of 8 tokens); every other part
+    // goes through a strided transpose of the finished row-major block.
     const int HD = a.H * D, M = a.B * a.S;
+    bf16* const dT = a.dT;
+    AttnArgs k = a;  // what the kernels see
+    const bool fused_t = dT && D == 128 && a.S % 8 == 0;
+    if (!fused_t) k.dT = nullptr;
     auto transpose_part = [&](int part, const bf16* src) -> int {
-        if (!a.dT) return 0;
-        return mmu_internal_transpose_strided(src, a.ldg, a.dT + (size_t)part * HD * a.ldt, a.ldt, M, HD, s);
+        return mmu_internal_transpose_strided(src, a.ldg, dT + (size_t)part * HD * a.ldt, a.ldt, M, HD, s);
     };
-    bool kv_t_done = false;
+    bool four_wave = false;
     if constexpr (D == 128) {
-        // 4 waves x 512 registers, persistent, K / V in registers, 4-stage Q/dO ring (attention_dkdv4.hip).  It takes
-        // sequences whose length is a multiple of 32 (each wave's 32 keys exist or none does: one unpredicated store
-        // path) and row strides that fit its 24-bit offset arithmetic; everything else goes to the eight-wave kernel.
-        if (g_dkdv_variant == 4 && a.S % 32 == 0 && a.ld < (1 << 23) && a.lddo < (1 << 23)) {
-            const int e4 = mmu_internal_launch_dkdv4(&a, CAUSAL ? 1 : 0, s);
+        // 4 waves x 512 registers, persistent, K / V in registers, 4-stage Q/dO ring (attention_dkdv4.hip); row strides
+        // must fit its 24-bit offset arithmetic, else the eight-wave kernel runs.
+        if (g_dkdv_variant == 4 && a.ld < (1 << 23) && a.lddo < (1 << 23)) {
+            const int e4 = mmu_internal_launch_dkdv4(&k, CAUSAL ? 1 : 0, s);
             if (e4) return e4;
-            kv_t_done = true;
+            four_wave = true;
         }
     }
-    if (!kv_t_done) {
-        hipLaunchKernelGGL((attn_bwd_dkdv_kernel<D, CAUSAL>), dim3(((a.S + 127) / 128) * a.H * a.B), dim3(512), LDS_KV, s, a);
+    if (!four_wave) {
+        hipLaunchKernelGGL((attn_bwd_dkdv_kernel<D, CAUSAL>), dim3(((a.S + 127) / 128) * a.H * a.B), dim3(512), LDS_KV, s, k);
         MMU_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<D, CAUSAL>), dim3(((a.S + 127) / 128) * a.H * a.B), dim3(256), LDS_DQ, s, a);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<D, CAUSAL>), dim3(((a.S + 127) / 128) * a.H * a.B), dim3(256), LDS_DQ, s, k);
     MMU_CHECK_LAUNCH();
-    if (a.dT) {
-        const bool q_t_done = D == 128 && a.S % 32 == 0;  // the dQ kernel's LDS-staged epilogue wrote dq^T
-        int e = q_t_done ? 0 : transpose_part(0, a.dq);
-        if (!e && !kv_t_done) e = transpose_part(1, a.dk);
-        if (!e && !kv_t_done) e = transpose_part(2, a.dv);
+    if (dT) {
+        int e = fused_t ? 0 : transpose_part(0, a.dq);
+        if (!e && !(fused_t && four_wave)) e = transpose_part(1, a.dk);
+        if (!e && !(fused_t && four_wave)) e = transpose_part(2, a.dv);
         if (e) return e;
     }
     return 0;

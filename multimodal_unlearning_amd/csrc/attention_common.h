@@ -192,6 +192,19 @@ __device__ __forceinline__ void store_grad_row(bf16* dst, const f32x16 (&acc)[4]
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+// 16-B global store under a per-lane predicate WITHOUT a branch and without the compiler seeing a store: EXEC is masked
+// and restored inside the statement.  For the persistent dK/dV kernel, where a predicated C++ store (s_cbranch_execz around
+// it) or any store the compiler still counts as outstanding brings `s_waitcnt vmcnt` into the step loop (see its header).
+// The caller drains with a real s_waitcnt vmcnt(0) before the stored registers are reused.
+__device__ __forceinline__ void store16_masked_asm(void* ptr, u32x4 val, int pred) {
+    unsigned long long m, keep;
+    asm volatile(
+        "v_cmp_ne_u32_e64 %0, 0, %2\n\ts_and_saveexec_b64 %1, %0\n\tglobal_store_dwordx4 %3, %4, off\n\ts_mov_b64 exec, %1"
+        : "=&s"(m), "=&s"(keep)
+        : "v"(pred), "v"(ptr), "v"(val)
+        : "memory", "scc");  // s_and_saveexec writes SCC
+}
+
 // A 32-row x 128-column bf16 tile held "row on the lane" — lane (row = lane & 31, hl = lane >> 5) holds w[dt][g] = the
 // four columns 32 dt + 8 g + 4 hl .. + 3 of its row, the layout of the dQ^T / dK^T / dV^T accumulators — written out
 // through a 4-KiB LDS area private to the wave, one 64-column half at a time:
@@ -201,14 +214,21 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 //    4 rows x 16 columns, every lane leaves with 4 consecutive rows of ONE column); two reads = 8 rows = 16 B of a row of
 //    the transposed matrix, a store instruction writes 16 such rows x 64 B.
 // Image: [row][16 granules of 8 B], granule ^= ((row >> 1) & 3) << 1.  g0 -> (first row, first column) of the row-major
-// destination (row stride ldg), t0 -> (first column, first row) of the transposed one (row stride ldt).  All 32 rows
-// are written, EXEC must be full (ds_read_b64_tr_b16), and nothing but this wave may touch xw[0, 4096).
+// destination (row stride ldg), t0 -> (first column, first row) of the transposed one (row stride ldt).  Rows
+// [0, rows_valid) are written (the transposed copy in whole groups of 8 rows: the caller only asks for it when the valid
+// row count is a multiple of 8); ASM_ST: the stores are store16_masked_asm.  EXEC must be full on entry
+// (ds_read_b64_tr_b16), and nothing but this wave may touch xw[0, 4096).
+template <bool ASM_ST>
 __device__ __forceinline__ void store_tile32x128_via_lds(MMU_LDS char* xw, const u32x2 (&w)[4][4], int lane, bf16* g0,
-                                                         int ldg, bf16* t0, int ldt) {
+                                                         int ldg, bf16* t0, int ldt, int rows_valid) {
     const int kr = lane & 31, rr = lane >> 3, hl = lane >> 5;
     const int w0 = kr * 128 + ((hl ^ (((kr >> 1) & 3) << 1)) << 3);
     const int r0 = rr * 128 + (((lane & 7) ^ ((rr >> 1) & 3)) << 4);
     bf16* gp = g0 + (size_t)rr * ldg + (lane & 7) * 8;
+    auto st = [&](bf16* dst, u32x4 v, bool ok) {
+        if (ASM_ST) store16_masked_asm(dst, v, ok ? 1 : 0);
+        else if (ok) *reinterpret_cast<u32x4*>(dst) = v;
+    };
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -219,7 +239,7 @@ __device__ __forceinline__ void store_tile32x128_via_lds(MMU_LDS char* xw, const
 #pragma unroll
         for (int i = 0; i < 4; ++i) rows[i] = *(const MMU_LDS u32x4*)(xw + r0 + i * 1024);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(gp + (size_t)i * 8 * ldg + h * 64) = rows[i];
+        for (int i = 0; i < 4; ++i) st(gp + (size_t)i * 8 * ldg + h * 64, rows[i], i * 8 + rr < rows_valid);
         if (t0) {
             const int g4 = lane >> 4, i16 = lane & 15;
             const int trow = 8 * g4 + (i16 >> 2);
@@ -231,7 +251,8 @@ __device__ __forceinline__ void store_tile32x128_via_lds(MMU_LDS char* xw, const
                 const int gi = 4 * cb + (i16 & 3);
                 const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((MMU_LDS bf16x4*)(xw + a0 + ((gi ^ sw0) << 3)));
                 const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((MMU_LDS bf16x4*)(xw + a1 + ((gi ^ sw1) << 3)));
-                *reinterpret_cast<bf16x8*>(tp + (size_t)(16 * cb) * ldt) = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                st(tp + (size_t)(16 * cb) * ldt, __builtin_bit_cast(u32x4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7)),
+                   8 * g4 + 8 <= rows_valid);
             }
         }
     }

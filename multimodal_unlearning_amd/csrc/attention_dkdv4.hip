@@ -68,11 +68,10 @@ constexpr int waitcnt_vm(int n) { return (n & 15) | ((n >> 4) << 14) | 0x0F70; }
 // At the end of an item each half matrix of dK / dV goes through a 4-KiB LDS area private to the wave so that a store
 // instruction writes 8 whole 128-B lines; the next item's K / V fragments are requested before those stores go out and
 // everything is drained once per item (a counted wait left hipcc guarding the stores' registers inside the step loop).
-// Sequence lengths that are not a multiple of 32 go to the eight-wave kernel (launch_bwd).
 // What the compiler must not be allowed to do here, each found the hard way (tools/attn_stamps.py, the .s):
 //  * two instantiations of the tile body -> dK / dV in different registers per path, 128 v_accvgpr_mov per step;
 //  * a branch between MFMA regions -> the VALU work of a region sinks into the next block, nothing overlaps it;
-//  * per-row predicated stores / `if (more)` around the next item's loads -> s_waitcnt vmcnt(15..0) in EVERY step
+//  * per-row predicated C++ stores / `if (more)` around the next item's loads -> s_waitcnt vmcnt(15..0) in EVERY step
 //    (the structurised control flow hides what is outstanding), i.e. a drain of the DMA ring per step;
 //  * a value kept live for the DMA (lane * 4) -> spilled to scratch, reloaded behind vmcnt(0) in every step.
 // Measured reason for the rebuild (tools/attn_stamps.py on the 8-wave kernel): 5 850 cycles per iteration for 2 x 1 024
@@ -430,8 +429,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv4_kernel(AttnArgs a, int 
         // issue (measured: 7.1 k cycles for the 16 of an item); instead each half matrix (32 keys x 64 d) goes through a
         // 4-KiB LDS area private to the wave — 8 ds_write_b64 in, 4 ds_read_b128 out with 8 lanes per key — so a store
         // instruction writes 8 whole 128-B lines.  [key][16 granules of 8 B], granule ^= ((key >> 1) & 3) << 1.
-        // One straight path of unpredicated stores: with a per-row predicate (and its skip branches) hipcc could no longer
-        // tell what is outstanding at the seam and re-checked the next item's K / V loads in every step of the loop.
+        // One straight path of stores: with a per-row predicate in C++ (and its skip branches) hipcc could no longer tell
+        // what is outstanding at the seam and re-checked the next item's K / V loads in every step of the loop.  Rows past
+        // the sequence end (a ragged last key block) are masked inside the store statement itself (store16_masked_asm).
         const bool stores = key0 < S;  // wave-uniform
         auto store_all = [&]() {
             MMU_LDS char* xw = (MMU_LDS char*)smem + XLDS + wave * 4096;
@@ -441,11 +441,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv4_kernel(AttnArgs a, int 
             const size_t g_off = row0 * a.ldg + out_hh * D;
             bf16* t_k = a.dT ? a.dT + ((size_t)a.H * D + out_hh * D) * a.ldt + row0 : nullptr;
             bf16* t_v = a.dT ? t_k + (size_t)a.H * D * a.ldt : nullptr;
-            store_tile32x128_via_lds(xw, wk, lane_e, a.dk + g_off, a.ldg, t_k, a.ldt);
-            store_tile32x128_via_lds(xw, wv, lane_e, a.dv + g_off, a.ldg, t_v, a.ldt);
+            const int rows_valid = min(32, S - key0);
+            store_tile32x128_via_lds<true>(xw, wk, lane_e, a.dk + g_off, a.ldg, t_k, a.ldt, rows_valid);
+            store_tile32x128_via_lds<true>(xw, wv, lane_e, a.dv + g_off, a.ldg, t_v, a.ldt, rows_valid);
         };
         const bool do_stores = !((DKDV4_EXP & 8) && a.scale != 12345.f);  // (the experiment keeps the stores reachable: no DCE)
-        // the launcher only takes this kernel for S % 32 == 0: a wave's 32 keys exist or none of them does
         if (stores && do_stores) store_all();
         STAMP(t_e3);
         // (a full drain, not vmcnt(16 stores): with stores still outstanding hipcc guards every register they read

@@ -192,7 +192,7 @@ def test_attn_fwd_left_pad_mask(dev):
                                                 (2, 3, 577, False, 0, 64), (1, 2, 130, True, 0, 64), (2, 2, 70, False, 9, 64),
                                                 (2, 4, 333, True, 0, 128), (1, 8, 1088, True, 0, 128),
                                                 (3, 8, 300, True, 37, 128), (2, 8, 450, False, 0, 128),
-                                                # multiples of 32 (the four-wave kernel's domain): ragged last 64-row stage,
+                                                # multiples of 32: whole waves with / without keys, ragged last 64-row stage,
                                                 # key blocks with waves that own no key, padding, several items per workgroup
                                                 (2, 4, 96, True, 0, 128), (3, 8, 288, True, 37, 128),
                                                 (2, 8, 416, False, 0, 128), (1, 16, 160, True, 5, 128),
@@ -241,7 +241,9 @@ def test_attn_bwd(dev, B, H, S, causal, pad, D, variant):
 
 @pytest.mark.parametrize("B,H,S,D,causal,use_rope", [(2, 4, 96, 128, True, True), (1, 8, 1088, 128, True, True),
                                                     (3, 8, 288, 128, True, False), (2, 3, 200, 128, True, True),
-                                                    (2, 8, 416, 128, False, False), (2, 3, 72, 64, False, False)])
+                                                    (2, 8, 416, 128, False, False), (2, 3, 72, 64, False, False),
+                                                    # sequence lengths that are not multiples of 8: strided-transpose fallback
+                                                    (2, 4, 100, 128, True, True), (8, 2, 333, 128, True, False)])
 @pytest.mark.parametrize("variant", [(8, 0), (4, 0), (4, 8)], ids=["w8", "w4", "w4-grid8"])
 def test_attn_bwd_transposed_copy(dev, B, H, S, D, causal, use_rope, variant):
     """mmu_attn_bwd_rope_t: dqkv_t == dqkv^T bit for bit (with and without the fused inverse RoPE), and dqkv itself is
