@@ -67,7 +67,7 @@ constexpr int waitcnt_vm(int n) { return (n & 15) | ((n >> 4) << 14) | 0x0F70; }
 // and VALU work pinned in it, see `tile` below.
 // At the end of an item each half matrix of dK / dV goes through a 4-KiB LDS area private to the wave so that a store
 // instruction writes 8 whole 128-B lines; the next item's K / V fragments are requested before those stores go out and
-// everything is drained once per item (a counted wait left hipcc guarding the stores' registers inside the step loop).
+// everything is drained once per item (with a counted wait hipcc kept re-checking the loads inside the step loop).
 // What the compiler must not be allowed to do here, each found the hard way (tools/attn_stamps.py, the .s):
 //  * two instantiations of the tile body -> dK / dV in different registers per path, 128 v_accvgpr_mov per step;
 //  * a branch between MFMA regions -> the VALU work of a region sinks into the next block, nothing overlaps it;
@@ -448,8 +448,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv4_kernel(AttnArgs a, int 
         const bool do_stores = !((DKDV4_EXP & 8) && a.scale != 12345.f);  // (the experiment keeps the stores reachable: no DCE)
         if (stores && do_stores) store_all();
         STAMP(t_e3);
-        // (a full drain, not vmcnt(16 stores): with stores still outstanding hipcc guards every register they read
-        // against reuse, which puts s_waitcnt vmcnt(11) .. vmcnt(0) into the step loop — a drain of the DMA ring in EVERY step)
+        // A full drain: the compiler only counts the K / V loads (the stores above are inside asm statements), so this is
+        // the wait that lets it consider them landed; the stores went out some thousand cycles ago and cost ~280 cycles of
+        // wait here (stamps).  Any weaker form left `s_waitcnt vmcnt(11) .. vmcnt(0)` in front of the loop's first writes to
+        // the registers the loads target — in EVERY step, i.e. a drain of the DMA ring per step.
         __builtin_amdgcn_s_waitcnt(waitcnt_vm(0));
         settle_kv();
 #ifdef MMU_ATTN_STAMP
