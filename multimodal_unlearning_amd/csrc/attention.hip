@@ -18,6 +18,10 @@
 // conflict-free for both ds_read_b128 row reads and transposed reads (guide T10 image (b)).
 #include "attention_common.h"
 
+#ifndef MMU_NO_KFLAG  // A/B only: 1 = a non-null key mask always takes the masked path (the behaviour before round 2)
+#define MMU_NO_KFLAG 0
+#endif
+
 namespace {
 
 // ------------------------------------------------------------------------------------------------
@@ -41,6 +45,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     const bf16* kp = a.k + rowbase * a.ld + hh * D;
     const bf16* vp = a.v + rowbase * a.ld + hh * D;
     float* kbias = reinterpret_cast<float*>(smem + 4 * TB);  // [2][64]
+    int* kflag = reinterpret_cast<int*>(smem + 4 * TB + 2 * 64 * 4);  // [2]: every key of the staged block is valid
 
     const int q0 = qb * 128 + wave * 32;
     const int qrow = q0 + (lane & 31);
@@ -79,6 +84,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
             const int key = kb * 64 + threadIdx.x;
             const bool ok = key < S && (a.kmask == nullptr || a.kmask[rowbase + key] != 0);
             kbias[buf * 64 + threadIdx.x] = ok ? 0.f : -INFINITY;
+            // a key mask that masks nothing in this block (the step passes device-resident masks it cannot inspect on the
+            // host: all ones without padding) must not cost the masked path: wave 0 leaves "all 64 keys valid" here
+            const bool all_ok = __all(ok);
+            if (threadIdx.x == 0) kflag[buf] = all_ok ? 1 : 0;
         }
     };
 
@@ -209,7 +218,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
         const bool active = !CAUSAL || (kb * 64 <= q0 + 31);
         if (active) {
             // wave-uniform: does any element of this block need a mask?
-            const bool masked = (CAUSAL && (kb * 64 + 63 > q0)) || (kb * 64 + 64 > S) || (a.kmask != nullptr);
+            const bool masked = (CAUSAL && (kb * 64 + 63 > q0)) || (kb * 64 + 64 > S) ||
+                                (a.kmask != nullptr && (MMU_NO_KFLAG || ((const MMU_LDS int*)kflag)[cur] == 0));
             block(masked, kb, cur);
         }
     }
@@ -286,6 +296,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     const bf16* vp = a.v + rowbase * a.ld + hh * D;
     const bf16* dop = a.dout + rowbase * a.lddo + hh * D;
     float* kbias = reinterpret_cast<float*>(smem + 4 * TB);
+    int* kflag = reinterpret_cast<int*>(smem + 4 * TB + 2 * 64 * 4);  // [2]: every key of the staged block is valid
 
     const int q0 = qb * 128 + wave * 32;
     const int qrow = q0 + (lane & 31);
@@ -324,6 +335,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
             const int key = kb * 64 + threadIdx.x;
             const bool ok = key < S && (a.kmask == nullptr || a.kmask[rowbase + key] != 0);
             kbias[buf * 64 + threadIdx.x] = ok ? 0.f : -INFINITY;
+            const bool all_ok = __all(ok);  // see attn_fwd_kernel: a mask that masks nothing here takes the plain path
+            if (threadIdx.x == 0) kflag[buf] = all_ok ? 1 : 0;
         }
     };
 
@@ -332,6 +345,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
         const int cur = kb & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        const bool keys_ok = ((const MMU_LDS int*)kflag)[cur] != 0;  // read before the next stage call rewrites the other slot
         if (kb + 1 < nblk) stage(kb + 1, cur ^ 1);
         if (kb > 0) {  // the fragment offsets follow the buffer (in-place XOR; tile bases are immediates below)
             fo.toggle_rows(2 * TB);
@@ -344,7 +358,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
             const MMU_LDS float* kbs = (const MMU_LDS float*)(smem + 4 * TB) + cur * 64;
             const bool diag = CAUSAL && (kb * 64 + 63 > q0);
             // wave-uniform: a block below the diagonal with 64 real, unmasked keys needs no bias, compare or select
-            const bool plain = !diag && (kb * 64 + 64 <= S) && a.kmask == nullptr;
+            const bool plain = !diag && keys_ok && !(MMU_NO_KFLAG && a.kmask != nullptr);  // (keys_ok: sequence end + key mask)
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
                 f32x16 s, dp;
@@ -724,7 +738,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
 
 template <int D, bool CAUSAL>
 int launch_fwd(const AttnArgs& a, hipStream_t s) {
-    constexpr int LDS = 4 * 64 * D * 2 + 2 * 64 * 4;
+    constexpr int LDS = 4 * 64 * D * 2 + 2 * 64 * 4 + 16;
     static bool cfg = false;
     if (!cfg) {
         int e = set_lds(attn_fwd_kernel<D, CAUSAL>, LDS);
@@ -743,7 +757,7 @@ static int g_dkdv_variant = MMU_DKDV_DEFAULT;  // mmu_attn_set_dkdv_variant: 8 =
 
 template <int D, bool CAUSAL>
 int launch_bwd(const AttnArgs& a, hipStream_t s) {
-    constexpr int LDS_DQ = 4 * 64 * D * 2 + 2 * 64 * 4;
+    constexpr int LDS_DQ = 4 * 64 * D * 2 + 2 * 64 * 4 + 16;
     constexpr int LDS_KV = 2 * 128 * D * 2 + 4 * 64 * D * 2 + 2 * 128 * 4;
     static bool cfg = false;
     if (!cfg) {
