@@ -1,7 +1,9 @@
-"""Where does a dK/dV workgroup spend its cycles?  Diagnostic build (-DMMU_ATTN_STAMP: s_memtime stamps around the
-prologue, the tile sweep, the loop-top waits and the epilogue of attn_bwd_dkdv_kernel, written to a buffer of their own;
-the real library has no stamp; the diagnostic build's run time is not quoted, only its shares).
-Usage: python tools/attn_stamps.py [B]"""
+"""Where does a dK/dV workgroup spend its cycles?  Diagnostic build (-DMMU_ATTN_STAMP: s_memtime stamps written to a
+buffer of their own; the real library has no stamp; the diagnostic build's run time is not quoted, only its shares).
+  python tools/attn_stamps.py [B]          eight-wave kernel: prologue, tile sweep, loop-top waits, epilogue per workgroup
+  python tools/attn_stamps.py --dkdv4 [B]  persistent four-wave kernel: per step (body, waits), per item (epilogue parts)
+ATTN_STAMP_LIB=<path> selects another diagnostic build, e.g. one made with -DDKDV4_EXP=<bits> (timing experiments that
+switch parts of the four-wave kernel off; see attention_dkdv4.hip)."""
 import ctypes as C, os, statistics, subprocess, sys, math
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
