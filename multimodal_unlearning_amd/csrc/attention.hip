@@ -327,10 +327,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     const int kv_end = CAUSAL ? min(S, qb * 128 + 128) : S;
     const int nblk = (kv_end + 63) / 64;
 
+    // K and V tiles share one set of precomputed per-lane offsets (same row stride, same row-read swizzle)
+    RowStager<D, KIND_ROW, 64> st_kv;
+    st_kv.init(a.ld, wave, lane);
     auto stage = [&](int kb, int buf) {
         char* base = smem + buf * 2 * TB;
-        stage_rows<D, KIND_ROW, 64>(base, kp, a.ld, kb * 64, S, wave, lane);
-        stage_rows<D, KIND_ROW, 64>(base + TB, vp, a.ld, kb * 64, S, wave, lane);
+        st_kv.issue(base, kp, a.ld, kb * 64, S, wave);
+        st_kv.issue(base + TB, vp, a.ld, kb * 64, S, wave);
         if (threadIdx.x < 64) {
             const int key = kb * 64 + threadIdx.x;
             const bool ok = key < S && (a.kmask == nullptr || a.kmask[rowbase + key] != 0);
