@@ -225,6 +225,24 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     }
     const float ltot = lsum + __shfl_xor(lsum, 32, 64);
     const float inv = ltot > 0.f ? 1.f / ltot : 0.f;
+    if constexpr (D == 128) {
+        // O leaves through LDS like the gradients of the backward kernels (store_tile32x128_via_lds: whole 128-B lines
+        // instead of 32 rows x 32 B per store instruction); the K / V buffers are free once every wave is out of the loop.
+        __syncthreads();
+        if (q0 < S) {
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[dt][r] *= inv;
+            u32x2 w[4][4];
+            grad_words(o, hl, nullptr, nullptr, w);
+            store_tile32x128_via_lds<false>((MMU_LDS char*)smem + wave * 4096, w, lane, a.o + (rowbase + q0) * a.ldo + hh * D,
+                                            a.ldo, nullptr, 0, min(32, S - q0));
+        }
+        if (qvalid && hl == 0 && a.lse)
+            a.lse[((size_t)b * a.H + hh) * S + qrow] = ltot > 0.f ? (m + __log2f(ltot)) * LN2 : INFINITY;
+        return;
+    }
     if (qvalid) {
         bf16* op = a.o + (rowbase + qrow) * a.ldo + hh * D;
 #pragma unroll
