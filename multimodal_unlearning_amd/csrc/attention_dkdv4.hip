@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv4_kernel(AttnArgs a, int 
             const int t = p & 3;
             const bool is_do = p >= 4;
             const unsigned row = (unsigned)min(4 * t + rr4, s_lim);
-            const unsigned voff = row * (is_do ? lddo2 : ldq2) + (chunk0 ^ (unsigned)(t << 4));
+            const unsigned voff = __umul24(row, is_do ? lddo2 : ldq2) + (chunk0 ^ (unsigned)(t << 4));  // full-rate 24-bit multiply
             glds16_sv(is_do ? s_do : s_q, voff, s_lds + (is_do ? TB : 0) + t * 1024);
         } else {
             const float* src = lane < s_rows ? s_rc + lane : reinterpret_cast<const float*>((wave & 1) ? mmu_zero16 : mmu_inf16);
