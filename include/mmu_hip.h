@@ -52,9 +52,16 @@ int mmu_fold_f32_into_bf16(float* src32, void* dst, const void* mask, long long 
 int mmu_gemm_set_tile(int tile);
 /* Tile rasterisation of the 256x256 kernel (tuning): GROUP_M tile rows swept column by column; 0 = default. */
 int mmu_gemm_set_group_m(int group_m);
-/* 256x256 kernel launch mode: 1 = persistent, 256 workgroups walk the tiles (default); 0 = one workgroup per tile
- * (A/B tests). */
+/* 256x256 kernel launch mode.  1 (default) = persistent: one workgroup per compute unit draws tiles from a device-side
+ * queue, so a workgroup whose CU is held by another kernel (RCCL's all-reduce during the overlapped gradient exchange of
+ * mm/forget.py:23-31's DDP counterpart) takes fewer tiles instead of delaying a fixed share; needs
+ * mmu_gemm_set_tile_queue, without it mode 1 launches one workgroup per tile.  0 = one workgroup per tile.
+ * 2 = persistent with a static tile walk (A/B tests: degrades badly when CUs are shared). */
 int mmu_gemm_set_persistent(int mode);
+/* Tile-queue counters of the persistent launch: device memory of >= mmu_gemm_tile_queue_bytes() (4 KiB), 16-B aligned,
+ * ZERO when registered (the kernels leave it zero); NULL unregisters.  The library never allocates. */
+int mmu_gemm_set_tile_queue(void* counters, long long bytes);
+long long mmu_gemm_tile_queue_bytes(void);
 /* Split-K tail of the 256x256 kernel: when the last (tiles % 256) tiles fill at most half a round of the 256 CUs, each
  * is cut into 256 / remainder K ranges on extra workgroups (fp32 partials in the workspace, reduced by a fold
  * kernel) instead of occupying a whole round.  mode 0 off, 1 heuristic (default), 2 whenever applicable.  The caller

@@ -26,7 +26,9 @@
 struct RopeReq { const int* pos; const bf16* cos; const bf16* sin; int cols; };
 static int g_force_tile = 0;  // mmu_gemm_set_tile
 static int g_group_m = 0;     // mmu_gemm_set_group_m
-static int g_persist = 1;     // mmu_gemm_set_persistent: 0 one workgroup per tile; 1 persistent (256 workgroups walk the tiles; default)
+static int g_persist = 1;     // mmu_gemm_set_persistent: 0 one workgroup per tile; 1 persistent, tiles drawn from a device-side queue (default); 2 persistent, static walk (A/B)
+static int* g_tileq = nullptr;   // mmu_gemm_set_tile_queue: TQ_SLOTS x 16 zeroed ints (8 per-XCD-class tile counters + 1 exit counter per slot)
+static unsigned g_tileq_seq = 0;  // launches take the slots round-robin, so kernels in flight on different streams never share one
 static int g_num_cu = 256;    // MI355X; replaced by the device's own count on the first launch (cu_count())
 static int g_tail_split = 1;     // mmu_gemm_set_tail_split: 0 off, 1 heuristic, 2 whenever the remainder is <= half a round
 static float* g_sk_ws = nullptr;  // mmu_gemm_set_workspace
@@ -69,6 +71,10 @@ struct GemmArgs {
     // a row / column still share their panels in L2 (a unit-balanced stream-K split loses that: measured 12 % slower).
     int sk_tiles, sk_first, sk_split;
     float* sk_ws;
+    // persistent launch with a tile queue: tq[c] (c = blockIdx.x & 7, the XCD class of the workgroup) counts the tiles
+    // of class c handed out so far (virtual tile ids c, c + 8, ...), tq[8] the workgroups that have left; the last one
+    // to leave zeroes the slot for the next launch that uses it.  nullptr: static walk vt, vt + grid, ...
+    int* tq;
 };
 
 __device__ __forceinline__ int swzT(int k) { return ((k & 3) << 1) | (((k >> 3) & 1) << 3); }
@@ -364,6 +370,7 @@ namespace g256 {
 
 constexpr int HB = 16384;  // bytes per half-tile
 constexpr int LDS_BYTES = 8 * HB;
+constexpr int TQ_SLOTS = 64;  // tile-queue slots of 16 ints (64 B) each
 
 // local row/col of a half-tile -> row/col of the 256-wide tile: 64-element runs stay contiguous so that a K-major
 // half-tile is fetched in whole 128-B lines.
@@ -511,7 +518,29 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     // Work of this workgroup: whole tiles (vt, then vt + grid in the persistent launch), or — split-K worker — one K
     // range [k0, k1) (in K-tiles) of one remainder tile.
     const bool sk_worker = p.sk_tiles > 0 && (int)blockIdx.x >= p.sk_first;
+    // Tile queue (persistent launch): a workgroup that the hardware starts late — its CU was held by another kernel, e.g.
+    // RCCL's all-reduce overlapping the last backward sweep — takes fewer tiles instead of keeping a fixed share waiting
+    // (static walk, 8 squatting workgroups: 2 446 -> 4 266 us on the qkv projection; profiles/r03_cu_contention_*.json).
+    // Thread 0 draws the next tile while the current one computes; the id crosses the waves through 4 bytes of LDS
+    // behind the tile buffers.
+    int* const tq = p.tq;
+    const int tq_class = blockIdx.x & 7;
+    volatile int* const tq_lds = reinterpret_cast<volatile int*>(smem + LDS_BYTES);
+    int tq_next = 0;
     int vt = blockIdx.x, k0 = 0, k1 = nk;
+    if (tq) {
+        if (threadIdx.x == 0) *tq_lds = tq_class + 8 * atomicAdd(tq + tq_class, 1);
+        __syncthreads();
+        vt = __builtin_amdgcn_readfirstlane(*tq_lds);
+        if (vt >= total_tiles) {  // more workgroups than tiles of this class: nothing left
+            if (threadIdx.x == 0 && atomicAdd(tq + 8, 1) == (int)gridDim.x - 1) {
+#pragma unroll
+                for (int i = 0; i < 9; ++i) tq[i] = 0;
+            }
+            return;
+        }
+        if (threadIdx.x == 0) tq_next = tq_class + 8 * atomicAdd(tq + tq_class, 1);
+    }
     if (sk_worker) {
         const int c = blockIdx.x - p.sk_first;
         const int kc = (nk + p.sk_split - 1) / p.sk_split;
@@ -526,10 +555,17 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
 
     int m0, n0;
     decode_tile(p, vt, m0, n0);
-    StageDesc dA0 = make_desc<AT, true>(p.A, p.lda, m0, 0, p.M, wave, lane);
-    StageDesc dA1 = make_desc<AT, true>(p.A, p.lda, m0, 1, p.M, wave, lane);
-    StageDesc dB0 = make_desc<BT, false>(p.B, p.ldb, n0, 0, p.N, wave, lane);
-    StageDesc dB1 = make_desc<BT, false>(p.B, p.ldb, n0, 1, p.N, wave, lane);
+#ifdef MMU_EXP_SAMETILE
+#define G256_SRC_M(m) 0
+#define G256_SRC_N(n) 0
+#else
+#define G256_SRC_M(m) (m)
+#define G256_SRC_N(n) (n)
+#endif
+    StageDesc dA0 = make_desc<AT, true>(p.A, p.lda, G256_SRC_M(m0), 0, p.M, wave, lane);
+    StageDesc dA1 = make_desc<AT, true>(p.A, p.lda, G256_SRC_M(m0), 1, p.M, wave, lane);
+    StageDesc dB0 = make_desc<BT, false>(p.B, p.ldb, G256_SRC_N(n0), 0, p.N, wave, lane);
+    StageDesc dB1 = make_desc<BT, false>(p.B, p.ldb, G256_SRC_N(n0), 1, p.N, wave, lane);
 
     f32x4 acc[2][2][2][4];  // [a][b][nt][mt]
     bf16x8 fa[2][4];     // [ks][mt]   current A block
@@ -565,6 +601,23 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
         __builtin_amdgcn_s_setprio(0);                                                                      \
     } while (0)
 
+    // Ceiling experiments (diagnostic builds only, tools/gemm_ceiling.py; results are WRONG on purpose): what the loop
+    // would deliver without its LDS fragment reads (MMU_EXP_NOLDSREAD), without its LDS-DMA traffic (MMU_EXP_NODMA), or
+    // with every tile's panels served by L2 (MMU_EXP_SAMETILE: all workgroups stream the panels of tile 0).
+#ifdef MMU_EXP_NOLDSREAD
+#define G256_LREAD_A(d, a) do { if (it == 0) { G256_READ_A(d, a); } } while (0)
+#define G256_LREAD_B(d, b) do { if (it == 0) { G256_READ_B(d, b); } } while (0)
+#else
+#define G256_LREAD_A(d, a) G256_READ_A(d, a)
+#define G256_LREAD_B(d, b) G256_READ_B(d, b)
+#endif
+#ifdef MMU_EXP_NODMA
+#define G256_LSTAGE_A(desc, d, h, kt) do { if (it == 0) { G256_STAGE_A(desc, d, h, kt); } } while (0)
+#define G256_LSTAGE_B(desc, d, h, kt) do { if (it == 0) { G256_STAGE_B(desc, d, h, kt); } } while (0)
+#else
+#define G256_LSTAGE_A(desc, d, h, kt) G256_STAGE_A(desc, d, h, kt)
+#define G256_LSTAGE_B(desc, d, h, kt) G256_STAGE_B(desc, d, h, kt)
+#endif
     // prologue: K-tile 0 complete in d0; B-h0, A-h0, B-h1 of K-tile 1 in flight towards d1
 #define G256_PROLOGUE()              \
     do {                             \
@@ -598,59 +651,66 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     for (int it = 0; it < niter; ++it) {
         const int t0 = 2 * it, t1 = t0 + 1;
         // ---- phase 1: B reads first so lgkmcnt(8) retires them before the barrier (B-h0 is restaged in phase 2)
-        G256_READ_B(0, 0);
+        G256_LREAD_B(0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        G256_READ_A(0, 0);
-        G256_STAGE_A(dA1, 1, 1, t1);
+        G256_LREAD_A(0, 0);
+        G256_LSTAGE_A(dA1, 1, 1, t1);
         G256_LGKM8();
         G256_BAR();
         G256_MMA(0, 0);
         G256_BAR();
         // ---- phase 2
-        G256_READ_B(0, 1);
-        G256_STAGE_B(dB0, 0, 0, t0 + 2);
+        G256_LREAD_B(0, 1);
+        G256_LSTAGE_B(dB0, 0, 0, t0 + 2);
         G256_BAR();
         G256_MMA(0, 1);
         G256_BAR();
         // ---- phase 3
-        G256_READ_A(0, 1);
-        G256_STAGE_A(dA0, 0, 0, t0 + 2);
+        G256_LREAD_A(0, 1);
+        G256_LSTAGE_A(dA0, 0, 0, t0 + 2);
         G256_BAR();
         G256_MMA(1, 1);
         G256_BAR();
         // ---- phase 4
-        G256_STAGE_B(dB1, 0, 1, t0 + 2);
+        G256_LSTAGE_B(dB1, 0, 1, t0 + 2);
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         G256_BAR();
         G256_MMA(1, 0);
         G256_BAR();
         // ---- phase 5
-        G256_READ_B(1, 0);
+        G256_LREAD_B(1, 0);
         __builtin_amdgcn_sched_barrier(0);
-        G256_READ_A(1, 0);
-        G256_STAGE_A(dA1, 0, 1, t0 + 2);
+        G256_LREAD_A(1, 0);
+        G256_LSTAGE_A(dA1, 0, 1, t0 + 2);
         G256_LGKM8();
         G256_BAR();
         G256_MMA(0, 0);
         G256_BAR();
         // ---- phase 6
-        G256_READ_B(1, 1);
-        G256_STAGE_B(dB0, 1, 0, t1 + 2);
+        G256_LREAD_B(1, 1);
+        G256_LSTAGE_B(dB0, 1, 0, t1 + 2);
         G256_BAR();
         G256_MMA(0, 1);
         G256_BAR();
         // ---- phase 7
-        G256_READ_A(1, 1);
-        G256_STAGE_A(dA0, 1, 0, t1 + 2);
+        G256_LREAD_A(1, 1);
+        G256_LSTAGE_A(dA0, 1, 0, t1 + 2);
         G256_BAR();
         G256_MMA(1, 1);
         G256_BAR();
         // ---- phase 8
-        G256_STAGE_B(dB1, 1, 1, t1 + 2);
+        G256_LSTAGE_B(dB1, 1, 1, t1 + 2);
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         G256_BAR();
         G256_MMA(1, 0);
         G256_BAR();
+    }
+    // Tile queue: the draw made when this tile started has long returned.  Thread 0 (a wm = 0 wave) publishes it BEFORE
+    // the balance barrier: that barrier pairs with the wm = 1 waves' last in-loop barrier, so every wave passes one
+    // barrier between this write and its read below and the hand-over costs no barrier of its own.
+    if (tq && threadIdx.x == 0) {
+        *tq_lds = tq_next;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     if (wm == 0) G256_BAR();  // balance the stagger barrier
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the overrun prefetches before the LDS is released
@@ -690,14 +750,19 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     const int cm0 = m0, cn0 = n0;
     const bool partial = sk_worker;  // a K range of a remainder tile: fp32 partial to the workspace
     const int slot = sk_worker ? (int)blockIdx.x - p.sk_first : 0;
-    vt += gridDim.x;
+    if (tq) {
+        vt = __builtin_amdgcn_readfirstlane(*tq_lds);
+        if (threadIdx.x == 0 && vt < total_tiles) tq_next = tq_class + 8 * atomicAdd(tq + tq_class, 1);
+    } else {
+        vt += gridDim.x;
+    }
     const bool more = p.sk_tiles == 0 && vt < total_tiles;  // persistent launch only
     if (more) {
         decode_tile(p, vt, m0, n0);
-        dA0 = make_desc<AT, true>(p.A, p.lda, m0, 0, p.M, wave, lane);
-        dA1 = make_desc<AT, true>(p.A, p.lda, m0, 1, p.M, wave, lane);
-        dB0 = make_desc<BT, false>(p.B, p.ldb, n0, 0, p.N, wave, lane);
-        dB1 = make_desc<BT, false>(p.B, p.ldb, n0, 1, p.N, wave, lane);
+        dA0 = make_desc<AT, true>(p.A, p.lda, G256_SRC_M(m0), 0, p.M, wave, lane);
+        dA1 = make_desc<AT, true>(p.A, p.lda, G256_SRC_M(m0), 1, p.M, wave, lane);
+        dB0 = make_desc<BT, false>(p.B, p.ldb, G256_SRC_N(n0), 0, p.N, wave, lane);
+        dB1 = make_desc<BT, false>(p.B, p.ldb, G256_SRC_N(n0), 1, p.N, wave, lane);
     }
 
     // Epilogue.  The MFMA leaves each lane with 4 consecutive columns of one row per (nt) tile: stored as is, a wave
@@ -759,6 +824,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     if (!more) break;
     G256_PROLOGUE();
   }
+    if (tq && threadIdx.x == 0 && atomicAdd(tq + 8, 1) == (int)gridDim.x - 1) {  // last workgroup out: every draw has been made
+#pragma unroll
+        for (int i = 0; i < 9; ++i) tq[i] = 0;
+    }
 #ifdef MMU_CLOCK_STAMP
     // the stamps leave through a buffer of their own that nothing else reads; no output depends on them
     if (threadIdx.x == 0 && blockIdx.x < 1024) {
@@ -767,6 +836,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     }
 #endif
 #undef G256_PROLOGUE
+#undef G256_LREAD_A
+#undef G256_LREAD_B
+#undef G256_LSTAGE_A
+#undef G256_LSTAGE_B
+#undef G256_SRC_M
+#undef G256_SRC_N
 #undef G256_BAR
 #undef G256_LGKM8
 #undef G256_STAGE_A
@@ -799,7 +874,7 @@ int launch_epi(GemmArgs a, hipStream_t stream) {
     auto kern = gemm256_kernel<AT, BT, EPI>;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + 16);
         if (e != hipSuccess) return (int)e;
         configured = true;
     }
@@ -830,14 +905,18 @@ int launch_epi(GemmArgs a, hipStream_t stream) {
         a.sk_first = tiles - rem;
         a.sk_split = split;
         a.sk_ws = g_sk_ws;
-        hipLaunchKernelGGL(kern, dim3(a.sk_first + rem * split), dim3(512), LDS_BYTES, stream, a);
+        hipLaunchKernelGGL(kern, dim3(a.sk_first + rem * split), dim3(512), LDS_BYTES + 16, stream, a);
         MMU_CHECK_LAUNCH();
         hipLaunchKernelGGL(sk_fold_kernel, dim3(rem, 64), dim3(256), 0, stream, a, EPI);  // one element group per thread
         MMU_CHECK_LAUNCH();
         return 0;
     }
-    const int grid = (g_persist && tiles > g_num_cu) ? g_num_cu : tiles;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS_BYTES, stream, a);
+    // persistent: mode 1 draws tiles from a queue slot (needs mmu_gemm_set_tile_queue; without one it is one workgroup
+    // per tile, which shares the GPU gracefully), mode 2 is the static walk
+    const bool persist = tiles > g_num_cu && (g_persist == 2 || (g_persist == 1 && g_tileq));
+    if (persist && g_persist == 1) a.tq = g_tileq + (size_t)(g_tileq_seq++ % TQ_SLOTS) * 16;
+    const int grid = persist ? g_num_cu : tiles;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS_BYTES + 16, stream, a);
     MMU_CHECK_LAUNCH();
     return 0;
 }
@@ -1017,10 +1096,18 @@ extern "C" int mmu_fold_f32_into_bf16(float* src32, void* dst, const void* mask,
 }
 
 extern "C" int mmu_gemm_set_persistent(int mode) {
-    if (mode < 0 || mode > 1) return -1;
+    if (mode < 0 || mode > 2) return -1;
     g_persist = mode;
     return 0;
 }
+// Device memory for the tile queues of the persistent launch: `bytes` >= mmu_gemm_tile_queue_bytes(), 16-B aligned and
+// ZERO when registered (the kernels leave it zero again); nullptr unregisters.  The library never allocates.
+extern "C" int mmu_gemm_set_tile_queue(void* counters, long long bytes) {
+    if (counters && (bytes < (long long)(g256::TQ_SLOTS * 16 * sizeof(int)) || ((uintptr_t)counters & 15))) return -1;
+    g_tileq = (int*)counters;
+    return 0;
+}
+extern "C" long long mmu_gemm_tile_queue_bytes(void) { return (long long)(g256::TQ_SLOTS * 16 * sizeof(int)); }
 
 // Split-K tail of the 256^2 kernel.  mode: 0 off, 1 when the model of saved rounds vs fold traffic says it pays
 // (default), 2 whenever the remainder tiles fill at most half a round (tests).  It needs a device workspace of at

@@ -358,4 +358,4 @@ extern "C" int mmu_scale_bf16(void* x, long long n, float s, void* stream) {
     return 0;
 }
 
-extern "C" int mmu_abi_version(void) { return 2; }
+extern "C" int mmu_abi_version(void) { return 3; }

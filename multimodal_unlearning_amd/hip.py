@@ -31,6 +31,7 @@ SIGNATURES = {
     "mmu_gemm_set_persistent": [_i],
     "mmu_gemm_set_tail_split": [_i],
     "mmu_gemm_set_workspace": [_vp, _ll],
+    "mmu_gemm_set_tile_queue": [_vp, _ll],
     "mmu_attn_fwd": [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp],
     "mmu_attn_bwd": [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i,
                      _vp],
@@ -221,16 +222,28 @@ _gemm_ws = None
 
 
 def ensure_gemm_workspace(device):
-    """Register the 64 MiB device workspace the split-K tail of the 256^2 GEMM needs (one per process = per GPU)."""
+    """Register the 64 MiB device workspace the split-K tail of the 256^2 GEMM needs and the 4 KiB of tile-queue
+    counters of its persistent launch (one per process = per GPU)."""
     global _gemm_ws
     if _gemm_ws is None or _gemm_ws.device != torch.device(device):
         lib = load()
         lib.mmu_gemm_workspace_bytes.restype = C.c_longlong
         lib.mmu_gemm_workspace_bytes.argtypes = []
         n = int(lib.mmu_gemm_workspace_bytes())
-        _gemm_ws = torch.empty(n, device=device, dtype=torch.uint8)
+        lib.mmu_gemm_tile_queue_bytes.restype = C.c_longlong
+        lib.mmu_gemm_tile_queue_bytes.argtypes = []
+        nq = int(lib.mmu_gemm_tile_queue_bytes())
+        _gemm_ws = torch.zeros(n + nq, device=device, dtype=torch.uint8)  # [split-K partials | zeroed tile-queue counters]
         _check(lib.mmu_gemm_set_workspace(_p(_gemm_ws), n), "mmu_gemm_set_workspace")
+        _check(lib.mmu_gemm_set_tile_queue(_gemm_ws.data_ptr() + n, nq), "mmu_gemm_set_tile_queue")
     return _gemm_ws
+
+
+def gemm_tile_queue_bytes() -> int:
+    lib = load()
+    lib.mmu_gemm_tile_queue_bytes.restype = C.c_longlong
+    lib.mmu_gemm_tile_queue_bytes.argtypes = []
+    return int(lib.mmu_gemm_tile_queue_bytes())
 
 
 def gemm_set_tile(tile: int):

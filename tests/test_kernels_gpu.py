@@ -747,18 +747,21 @@ def test_clip_normalize_u8_matches_processor(dev):
 
 
 def test_gemm256_persistent_launch_matches(dev):
-    """Persistent launch of the 256^2 kernel (256 workgroups walking 17x17 ragged tiles) == one workgroup per tile,
-    for the plain, bias+residual and accumulate epilogues (all through the swapped 16-B-store epilogue)."""
+    """Persistent launches of the 256^2 kernel (one workgroup per CU over 17x17 ragged tiles; mode 1 draws tiles from the
+    device-side queue, mode 2 walks them statically) == one workgroup per tile, for the plain, bias+residual and
+    accumulate epilogues (all through the swapped 16-B-store epilogue).  The queue counters are left zero."""
     M, N, K = 4200, 4344, 328
     A = _rand_int((M, K), dev, -2, 2, seed=11)
     Bm = _rand_int((N, K), dev, -2, 2, seed=12)
     bias = _rand_int((N,), dev, -3, 3, seed=13)
     resid = _rand_int((M, N), dev, -3, 3, seed=14)
     ref = A.float() @ Bm.float().t()
+    ws = hip.ensure_gemm_workspace(dev)
+    nq = hip.gemm_tile_queue_bytes()
     hip.gemm_set_tile(256)
     try:
         outs = []
-        for mode in (0, 1):
+        for mode in (0, 1, 2):
             hip.gemm_set_persistent(mode)
             c0 = torch.empty(M, N, device=dev, dtype=BF)
             hip.gemm(hip.NT, A, Bm, c0)
@@ -767,13 +770,38 @@ def test_gemm256_persistent_launch_matches(dev):
             c2 = resid.clone()
             hip.gemm(hip.NT, A, Bm, c2, accumulate=True)
             outs.append((c0, c1, c2))
-        for x, y in zip(*outs):
-            assert torch.equal(x, y)
+        for other in outs[1:]:
+            for x, y in zip(outs[0], other):
+                assert torch.equal(x, y)
         assert torch.equal(outs[0][0], ref.to(BF))
         assert torch.equal(outs[0][1], ((ref + bias.float()).to(BF).float() + resid.float()).to(BF))
         assert torch.equal(outs[0][2], (ref + resid.float()).to(BF))
+        assert int(ws[-nq:].view(torch.int32).abs().sum()) == 0
     finally:
         hip.gemm_set_persistent(1)  # the default
+        hip.gemm_set_tile(0)
+
+
+def test_gemm256_tile_queue_many_launches_and_few_tiles(dev):
+    """The tile queue over more launches than it has slots (64), with fewer tiles than workgroups in some XCD classes
+    (a 3 x 90 tile grid = 270 tiles on 256 workgroups: classes 0..5 hold 34 tiles for 32 workgroups, 6..7 hold 33) and
+    with a tile count that is not a multiple of 8: every launch exact, counters zero at the end."""
+    hip.gemm_set_tile(256)
+    ws = hip.ensure_gemm_workspace(dev)
+    nq = hip.gemm_tile_queue_bytes()
+    try:
+        hip.gemm_set_persistent(1)
+        for (M, N, K) in ((700, 23040, 192), (256 * 17 - 8, 256 * 17 - 8, 128)):
+            A = _rand_int((M, K), dev, -2, 2, seed=41)
+            Bm = _rand_int((N, K), dev, -2, 2, seed=42)
+            ref = (A.float() @ Bm.float().t()).to(BF)
+            outs = [torch.empty(M, N, device=dev, dtype=BF) for _ in range(70)]
+            for c in outs:
+                hip.gemm(hip.NT, A, Bm, c)
+            for c in outs[::23] + [outs[-1]]:
+                assert torch.equal(c, ref)
+        assert int(ws[-nq:].view(torch.int32).abs().sum()) == 0
+    finally:
         hip.gemm_set_tile(0)
 
 

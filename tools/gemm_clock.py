@@ -6,9 +6,12 @@ has no stamp.  Usage: python tools/gemm_clock.py [out.json]   (builds the varian
 import ctypes as C, json, os, statistics, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-lib = os.path.join(ROOT, "multimodal_unlearning_amd", "csrc", "variants", "libmmu_hip_clock.so")
+# GEMM_CLOCK_VARIANT / GEMM_CLOCK_FLAGS: the same measurement on another diagnostic build (tools/gemm_ceiling.py)
+variant = os.environ.get("GEMM_CLOCK_VARIANT", "clock")
+lib = os.path.join(ROOT, "multimodal_unlearning_amd", "csrc", "variants", f"libmmu_hip_{variant}.so")
 if not os.path.exists(lib):
-    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "build_variant.py"), "clock", "-DMMU_CLOCK_STAMP"], check=True)
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "build_variant.py"), variant, "-DMMU_CLOCK_STAMP",
+                    *os.environ.get("GEMM_CLOCK_FLAGS", "").split()], check=True)
 os.environ["MMU_HIP_LIB"] = lib
 import torch
 from multimodal_unlearning_amd import hip
