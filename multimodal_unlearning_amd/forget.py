@@ -138,7 +138,7 @@ class _JsonlText:
         from transformers import AutoTokenizer
 
         from .collator import TokenizerAdapter
-        from .text_collator import TextForgetPairs
+        from .text_collator import TextForgetPairs, TextForgetTriples
 
         read = lambda p: [json.loads(line) for line in open(p) if line.strip()]
         tok = AutoTokenizer.from_pretrained(tokenizer_path, local_files_only=True)
@@ -146,9 +146,15 @@ class _JsonlText:
         idk_path = os.path.join(os.path.dirname(rc.forget_data_path), "idontknow.jsonl")
         if os.path.exists(idk_path):
             idk = [line.strip() for line in open(idk_path) if line.strip()]
-        self.pairs = TextForgetPairs(read(rc.forget_data_path), read(rc.retain_data_path), TokenizerAdapter.from_hf(tok),
-                                     tok.eos_token_id, max_length=rc.seq_len or 500, loss_type=rc.forget_loss,
-                                     idk_answers=idk)
+        if rc.forget_loss in ("dpo", "LLMU"):  # nlp/forget.py:63-70: TextForgetDatasetDPOQA ([idk, forget, retain] items)
+            if not idk:
+                raise SystemExit(f"forget_loss={rc.forget_loss} needs idontknow.jsonl next to {rc.forget_data_path}")
+            self.pairs = TextForgetTriples(read(rc.forget_data_path), read(rc.retain_data_path), TokenizerAdapter.from_hf(tok),
+                                           tok.eos_token_id, max_length=rc.seq_len or 500, idk_answers=idk)
+        else:
+            self.pairs = TextForgetPairs(read(rc.forget_data_path), read(rc.retain_data_path), TokenizerAdapter.from_hf(tok),
+                                         tok.eos_token_id, max_length=rc.seq_len or 500, loss_type=rc.forget_loss,
+                                         idk_answers=idk)
 
     def __len__(self):
         return len(self.pairs)
@@ -210,6 +216,10 @@ def run(rc: ForgetRunConfig):
     from .llava import LlavaHIP, LoraSpec
     from .trainer import CustomTrainerForgetting, MMTrainerForgetting
 
+    # mm/forget.py:40-44 "Directory already exists": decided BEFORE the rendezvous from the launcher's env, so that every
+    # rank leaves (a rank-0-only exit after init_process_group would strand the others in their first collective)
+    if os.path.exists(rc.save_dir) and not rc.overwrite_dir:
+        raise SystemExit("Directory already exists")
     rank, local, world = init_distributed()
     if not torch.cuda.is_available():
         raise SystemExit("the forget step runs on MI355X GPUs (HIP kernels; there is no CPU path)")
@@ -222,8 +232,6 @@ def run(rc: ForgetRunConfig):
     log(f"num_devices: {world}")
     log("######################\nSaving to: ", rc.save_dir, "\n######################")
     if rank == 0:
-        if os.path.exists(rc.save_dir) and not rc.overwrite_dir:
-            raise SystemExit("Directory already exists")
         os.makedirs(rc.save_dir, exist_ok=True)
         import yaml
 
@@ -258,7 +266,14 @@ def run(rc: ForgetRunConfig):
         max_steps = rc.max_steps
     log(f"max_steps: {max_steps}")
 
-    lora = LoraSpec(r=rc.lora_r, alpha=rc.lora_alpha) if rc.lora_r else None
+    # mm/forget.py:126: adapters only when `LoRA.r != 0 and (l_norm_from != "zero" or l1_lambda == 0)`; an L1 penalty on
+    # the distance from zero with LoRA.r set silently runs FULL fine-tuning in the reference, and so does this
+    use_lora = rc.lora_r != 0 and (rc.l_norm_from != "zero" or rc.l1_lambda == 0)
+    if rc.lora_r != 0 and not use_lora:
+        log(f"LoRA.r={rc.lora_r} ignored: l1_lambda={rc.l1_lambda} with l_norm_from=zero runs full fine-tuning (mm/forget.py:126)")
+    if use_lora and rc.lora_dropout != 0:
+        raise SystemExit("LoRA.dropout != 0 is not implemented (the reference's default is 0.0, config/mm/forget.yaml:6)")
+    lora = LoraSpec(r=rc.lora_r, alpha=rc.lora_alpha) if use_lora else None
     need_teacher = bool(rc.l1_lambda or rc.l0_lambda) or tu.loss_needs_teacher(lt)
     params = extra = None
     if _has_checkpoint(rc.model_path):
@@ -281,15 +296,19 @@ def run(rc: ForgetRunConfig):
                           dp_mode=rc.dp_mode)
 
     mine = shard_indices(len(data), rank, world)
+    if not mine:
+        raise SystemExit(f"rank {rank}: no samples ({len(data)} items on {world} ranks)")
     per_step = rc.batch_size * rc.gradient_accumulation_steps
     order_rng = random.Random(rc.seed)
     t0, seen, cursor, order = time.perf_counter(), 0, 0, []
     for step in range(max_steps):
         mbs = []
         for _ in range(rc.gradient_accumulation_steps):
-            if cursor + rc.batch_size > len(order):  # next epoch: reshuffle this rank's shard
-                order = order[cursor:] + order_rng.sample(mine, len(mine))
+            if cursor + rc.batch_size > len(order):  # next epoch(s): reshuffle this rank's shard until a batch is full
+                order = order[cursor:]
                 cursor = 0
+                while len(order) < rc.batch_size:
+                    order = order + order_rng.sample(mine, len(mine))
             mbs.append(data.batch(order[cursor:cursor + rc.batch_size], dev))
             cursor += rc.batch_size
         st = engine.step(mbs, sync_loss=True)

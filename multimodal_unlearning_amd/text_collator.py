@@ -5,7 +5,7 @@ Counterparts of /root/reference/nlp/data_module.py:10-43 (`convert_raw_data_to_m
 fixed length, RIGHT padding with the EOS id, labels = ids with the question span and all padding but the first EOS
 ignored), :46-94 (`TextForgetDatasetQA.__getitem__`: each forget item is paired with the retain item
 `(idx + randint(len(retain))) % len(retain)`; the "idk" split answers a forget question with a random line of
-idontknow.jsonl) and /root/reference/nlp/dataloader.py:497-517 (`custom_data_collator_forget`: per split, stack the
+idontknow.jsonl), :97-130 (`TextForgetDatasetDPOQA`, the dpo / LLMU dataset) and /root/reference/nlp/dataloader.py:497-517 (`custom_data_collator_forget`: per split, stack the
 (input_ids, labels, attention_mask) tuples).  No dataset or tokenizer is fetched: rows and the tokenizer come from the
 caller (`TokenizerAdapter`, collator.py).  Pinned by tests/golden/text_collator.npz, generated from the reference's own
 functions (oracle/make_golden_text_collator.py).
@@ -67,6 +67,38 @@ class TextForgetPairs:
             question, answer = data[idx]["question"], data[idx]["answer"]
             if data_type == "idk":
                 answer = self.idk[torch.randint(0, len(self.idk), (1,)).item()].strip()
+            rets.append(convert_raw_data_to_model_format(self.tok, self.eos, self.max_length, question, answer, self.tags))
+        return rets
+
+
+class TextForgetTriples:
+    """`TextForgetDatasetDPOQA` (nlp/data_module.py:97-130), what nlp/forget.py:63-70 builds for forget_loss "dpo" and
+    "LLMU": every item is [idk, forget, retain] IN THAT ORDER — the forget question answered by a random line of
+    idontknow.jsonl, the forget pair, a retain pair at `(idx + randint) % len(retain)`.  The collator below names the
+    POSITIONS (forget, retain, idk), so downstream the first tuple the trainer calls "forget" holds the idk answers; that
+    is the reference's behaviour and is reproduced, not corrected (tests/golden/text_collator.npz: item.dpo.*)."""
+
+    def __init__(self, forget_rows: Sequence[dict], retain_rows: Sequence[dict], tok: TokenizerAdapter, eos_token_id: int,
+                 max_length: int = 500, idk_answers: Sequence[str] = (), tags: Dict[str, str] = LLAMA2_TAGS):
+        if not idk_answers:
+            raise ValueError("dpo / LLMU need the idk answers (the reference reads data/idontknow.jsonl)")
+        self.forget_data, self.retain_data, self.idk = forget_rows, retain_rows, list(idk_answers)
+        self.tok, self.eos, self.max_length, self.tags = tok, eos_token_id, max_length, tags
+
+    def __len__(self):
+        return len(self.forget_data)
+
+    def __getitem__(self, idx: int):
+        rets = []
+        for data_type in ("idk", "forget", "retain"):
+            data = self.retain_data if data_type == "retain" else self.forget_data
+            if data_type == "retain":
+                idx = (idx + torch.randint(0, len(self.retain_data), (1,)).item()) % len(self.retain_data)
+            question = data[idx]["question"]
+            if data_type == "idk":
+                answer = self.idk[torch.randint(0, len(self.idk), (1,)).item()].strip()
+            else:
+                answer = data[idx]["answer"]
             rets.append(convert_raw_data_to_model_format(self.tok, self.eos, self.max_length, question, answer, self.tags))
         return rets
 

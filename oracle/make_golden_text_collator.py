@@ -1,6 +1,7 @@
 """ORACLE fixture generator #6 (build container only; needs /root/reference + transformers):
 the text trainer's data path — /root/reference/nlp/data_module.py:10-43 `convert_raw_data_to_model_format`, :46-94
-`TextForgetDatasetQA.__getitem__` (called unbound on in-memory rows: the class itself loads TOFU from the hub) and
+`TextForgetDatasetQA.__getitem__`, :97-130 `TextForgetDatasetDPOQA.__getitem__` (called unbound on in-memory rows: the
+classes themselves load TOFU from the hub) and
 /root/reference/nlp/dataloader.py:497-517 `custom_data_collator_forget` — on a tiny offline tokenizer
 -> tests/golden/text_collator.npz.
 Usage: PYTHONPATH=/root/reference:/root/reference/nlp:/root/repo python oracle/make_golden_text_collator.py
@@ -68,6 +69,17 @@ def main():
             res[f"collated.{loss_type}"] = np.stack([np.stack([t.numpy() for t in split]) for split in col])
         except Exception as e:  # the module imports the whole trainer stack; record why if that fails
             print("custom_data_collator_forget not importable:", repr(e))
+    # nlp/forget.py:63-70: dpo / LLMU runs use TextForgetDatasetDPOQA, whose items are [idk, forget, retain] IN THAT ORDER
+    # while custom_data_collator_forget names the positions (forget, retain, idk)
+    fake = types.SimpleNamespace(tokenizer=tok, max_length=24, forget_data=ROWS_F, retain_data=ROWS_R, model_configs=cfgs,
+                                 idk=[x + "\n" for x in IDK])
+    torch.manual_seed(4321)
+    items = [dm.TextForgetDatasetDPOQA.__getitem__(fake, i) for i in range(len(ROWS_F))]
+    for i, it in enumerate(items):
+        res[f"item.dpo.{i}"] = np.stack([np.stack([t.numpy() for t in split]) for split in it])
+    import importlib
+    col = importlib.import_module("dataloader").custom_data_collator_forget(items)
+    res["collated.dpo"] = np.stack([np.stack([t.numpy() for t in split]) for split in col])
     path = os.path.join(ROOT, "tests", "golden", "text_collator.npz")
     np.savez_compressed(path, **res)
     print("wrote", path, os.path.getsize(path), sorted(res)[:4], "...")

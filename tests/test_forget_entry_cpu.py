@@ -30,3 +30,14 @@ def test_entry_refuses_to_run_without_a_gpu(monkeypatch):
     with pytest.raises(SystemExit) as e:
         main(["model_family=tiny", "save_dir=/tmp/mmu_never_written", "forget_data_path=synthetic:8"])
     assert "MI355X" in str(e.value)
+
+
+def test_existing_directory_is_refused_before_the_rendezvous(tmp_path, monkeypatch):
+    """mm/forget.py:40-44 with overwrite_dir=false: every rank must leave, so the check runs before init_process_group
+    (WORLD_SIZE=2 here: a rendezvous attempt would hang the test instead of raising)."""
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setenv("RANK", "1")
+    monkeypatch.setenv("LOCAL_RANK", "1")
+    with pytest.raises(SystemExit) as e:
+        main(["model_family=tiny", f"save_dir={tmp_path}", "overwrite_dir=false", "forget_data_path=synthetic:8"])
+    assert "Directory already exists" in str(e.value)

@@ -9,7 +9,7 @@ import pytest
 import torch
 
 from multimodal_unlearning_amd.collator import TokenizerAdapter
-from multimodal_unlearning_amd.text_collator import (TextForgetPairs, convert_raw_data_to_model_format,
+from multimodal_unlearning_amd.text_collator import (TextForgetPairs, TextForgetTriples, convert_raw_data_to_model_format,
                                                       custom_data_collator_forget)
 from oracle.make_golden_text_collator import EXTRA, IDK, ROWS_F, ROWS_R
 from oracle.tiny_tokenizer import build_tokenizers_object
@@ -44,6 +44,22 @@ def test_pairing_and_collator_match_reference(tok, loss_type):
     got = np.stack([np.stack([t.numpy() for t in split]) for split in col])
     assert np.array_equal(got, G[f"collated.{loss_type}"])
     assert len(col) == 2 and col[0][0].shape == (len(ROWS_F), 24)
+
+
+def test_dpo_triples_match_reference(tok):
+    """TextForgetDatasetDPOQA (dpo / LLMU): items [idk, forget, retain], collated position-wise into three splits."""
+    ds = TextForgetTriples(ROWS_F, ROWS_R, tok, EOS, max_length=24, idk_answers=IDK)
+    torch.manual_seed(4321)
+    items = [ds[i] for i in range(len(ds))]
+    for i, it in enumerate(items):
+        got = np.stack([np.stack([t.numpy() for t in split]) for split in it])
+        assert np.array_equal(got, G[f"item.dpo.{i}"]), i
+    col = custom_data_collator_forget(items)
+    got = np.stack([np.stack([t.numpy() for t in split]) for split in col])
+    assert np.array_equal(got, G["collated.dpo"])
+    assert len(col) == 3
+    with pytest.raises(ValueError):
+        TextForgetTriples(ROWS_F, ROWS_R, tok, EOS)
 
 
 def test_collator_keeps_an_optional_third_split(tok):

@@ -9,7 +9,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from multimodal_unlearning_amd import hip
-sq = C.CDLL(os.path.join(ROOT, "tools", "csrc", "libsquatter.so"))
+_so = os.path.join(ROOT, "tools", "csrc", "libsquatter.so")
+if not os.path.exists(_so):
+    import subprocess
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-shared", "-fPIC", "-o", _so,
+                    os.path.join(ROOT, "tools", "csrc", "squatter.hip")], check=True)
+sq = C.CDLL(_so)
 sq.squat_launch.argtypes = [C.c_int, C.c_int, C.c_longlong, C.c_void_p]
 sq.squat_launch.restype = C.c_int
 dev = torch.device("cuda:0")

@@ -2,7 +2,7 @@
 # HBM traffic of the GEMM kernels of one bench step via rocprofv3 PMC (separate passes: FETCH_SIZE, WRITE_SIZE;
 # kernel-trace only, no other trace domains).  Output: gpurun_out/pmc_bench/traffic.json
 export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (the repo root on the GPU box)}
 OUT=$R/gpurun_out/pmc_bench
 mkdir -p $OUT
 cd /tmp

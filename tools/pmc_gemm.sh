@@ -1,7 +1,7 @@
 #!/bin/bash
 # PMC passes for representative GEMM cases (separate rocprofv3 runs per counter group, kernel-trace only).
 export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (the repo root on the GPU box)}
 OUT=$R/gpurun_out/pmc_gemm
 mkdir -p $OUT
 cd /tmp

@@ -1,6 +1,6 @@
 #!/bin/bash
 export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (the repo root on the GPU box)}
 OUT=$R/gpurun_out/pmc_gemm2
 mkdir -p $OUT
 cd /tmp

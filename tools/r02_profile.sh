@@ -3,7 +3,7 @@
 # default bench line, rocprofv3 kernel stats of the same command, PMC traffic of the GEMM launches, PMC MFMA-busy /
 # wait breakdown of the attention and GEMM kernels.  Usage: bash tools/r02_profile.sh
 export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (the repo root on the GPU box)}
 O=$R/gpurun_out/r02
 mkdir -p $O
 cd $R
