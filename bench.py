@@ -31,14 +31,16 @@ import torch.distributed as dist  # noqa: E402
 PEAK_BF16 = 2.5e15  # dense bf16 MFMA FLOP/s per MI355X
 
 
-def flops_per_sample(cfg, S, paired=True, lora=False, text_only=False, forward_only=False):
-    """Algorithmic FLOPs of one grad_diff full-FT sample (forget + retain sequence), vision tower frozen:
-    matmul = 2mnk, causal attention at half the dense S^2."""
+def flops_per_sample(cfg, S, paired=True, lora=False, text_only=False, forward_only=False, head_rows=None):
+    """FLOPs of one grad_diff full-FT sample (forget + retain sequence), vision tower frozen: matmul = 2mnk, causal
+    attention at half the dense S^2.  head_rows: rows per sequence that go through the lm_head
+    (None = all S positions, SURVEY §8d's algorithmic count; the loss-only forward runs the supervised rows only and
+    the step is priced with the FLOPs it EXECUTES)."""
     t, v = cfg.text, cfg.vision
     d, I, L, V = t.hidden_size, t.intermediate_size, t.num_layers, t.vocab_size
     lin = 2 * S * (4 * d * d + 3 * d * I) * L
     attn = 2 * 2 * S * S * d * L / 2
-    head = 2 * S * d * V
+    head = 2 * (S if head_rows is None else head_rows) * d * V
     dec = lin + attn + head
     T = v.num_patches + 1
     dv, iv = v.hidden_size, v.intermediate_size
@@ -286,6 +288,9 @@ def main():
                     help="gradient exchange at N > 1: bucketed all-reduce overlapped with backward (default), or "
                          "reduce-scatter + sharded AdamW state + parameter all-gather (ZeRO-style, state / N)")
     ap.add_argument("--no-fuse", action="store_true")
+    ap.add_argument("--full-logits", action="store_true",
+                    help="A/B: every forward materialises all logits (round-2 behaviour); default: forwards of which only "
+                         ".loss is read run final norm + lm_head + CE on the supervised rows")
     ap.add_argument("--no-wt", action="store_true", help="do not keep resident W^T copies (saves one weight copy of HBM)")
     ap.add_argument("--lora-r", type=int, default=0, help="LoRA rank (0 = full fine-tuning); BASELINE config 2 uses 8")
     ap.add_argument("--lora-alpha", type=float, default=32.0)
@@ -335,10 +340,11 @@ def main():
     splits = ("forget", "retain", "idk") if any(k in args.loss.lower() for k in ("idk", "dpo", "llmu")) else ("forget", "retain")
     if args.text_only:
         tr = CustomTrainerForgetting(model=model, forget_loss=args.loss, oracle_model=teacher, loss_beta=1.0, l1_lambda=0.0,
-                                     l0_lambda=0.0, loss_args={"fuse_pairs": not args.no_fuse})
+                                     l0_lambda=0.0, loss_args={"fuse_pairs": not args.no_fuse, "loss_only_head": not args.full_logits})
     else:
         tr = MMTrainerForgetting(model=model, forget_loss=args.loss, teacher_model=teacher, loss_beta=1.0, l1_lambda=0.0,
-                                 l0_lambda=0.0, l_norm_from="zero", loss_args={"fuse_pairs": not args.no_fuse})
+                                 l0_lambda=0.0, l_norm_from="zero",
+                                 loss_args={"fuse_pairs": not args.no_fuse, "loss_only_head": not args.full_logits})
     fcfg = ForgetConfig(batch_size=args.micro_batch, gradient_accumulation_steps=args.grad_accum)
     eng = ForgetEngine(model, tr, fcfg, total_steps=args.steps + args.warmup + 1, warmup_steps=1,
                        transposed_weights=not args.no_wt, optimizer=args.optim, dp_mode=args.dp_mode)
@@ -416,11 +422,21 @@ def main():
         value = samples / elapsed
         lt = args.loss.lower()
         paired = lt not in ("grad_ascent", "retain_ft", "npo")
-        fps = flops_per_sample(cfg, S, paired=paired, lora=bool(args.lora_r), text_only=args.text_only)
+        # rows per sequence that reach the lm_head: the supervised positions (incl. the padding slots of the fixed-capacity
+        # row list) when every student forward of the loss is a loss-only forward, else all S
+        head_rows = None
+        if not args.full_logits and lt in ("grad_diff_forget_ce_retain_ce", "grad_ascent", "retain_ft", "idk", "eco_ft"):
+            from multimodal_unlearning_amd.llava import supervised_rows
+            first = mbs[0]
+            labs = [sp[1] for sp in first] if args.text_only else [sp["labels"] for sp in first.values()]
+            head_rows = sum(supervised_rows(x.cpu(), cfg.text.vocab_size, "cpu")[2] for x in labs) / len(labs)
+        fps_alg = flops_per_sample(cfg, S, paired=paired, lora=bool(args.lora_r), text_only=args.text_only)
+        fps = flops_per_sample(cfg, S, paired=paired, lora=bool(args.lora_r), text_only=args.text_only, head_rows=head_rows)
         # teacher forwards (no grad): npo 1, kl 1, scrub 2, grad_diff_*_kl 1 per kl side
         t_fwd = {"npo": 1, "kl": 1, "scrub": 2, "llmu": 1}.get(lt, lt.count("_kl") if lt.startswith("grad_diff") else 0)
         if t_fwd:
             fps += t_fwd * flops_per_sample(cfg, S, text_only=args.text_only, forward_only=True)
+            fps_alg += t_fwd * flops_per_sample(cfg, S, text_only=args.text_only, forward_only=True)
         f, t, n, by = timer.summary()
         # HBM-side bytes per GEMM launch (rocprofv3 PMC: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate passes; counts L2
         # misses incl. Infinity-Cache hits).  PMC collection cannot run inside the timed process, so the figure is
@@ -468,6 +484,9 @@ def main():
                    "gradient_bytes_per_step": model.train_flat.numel() * 2,
                    "exposed_exchange_ms_per_step": [round(x, 2) for x in rank_exch_ms] if world > 1 else None},
             "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 1e9, 1),
+            # priced with the FLOPs the step EXECUTES (fps); SURVEY §8d's algorithmic count, which charges the lm_head for
+            # every position, is reported next to it
+            "flops_per_sample_executed": fps, "flops_per_sample_algorithmic": fps_alg, "lm_head_rows_per_sequence": head_rows or S,
             "step_tflops_per_gpu": round(value * fps / world / 1e12, 1),
             "step_frac_of_mfma_peak": round(value * fps / world / PEAK_BF16, 4),
             "roofline": {"bound": "mfma", "achieved": round(f / t / 1e12, 1), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",

@@ -183,6 +183,12 @@ int mmu_rowloss_bwd(int mode, const void* slog, const void* tlog, int ldv, float
  * rows: device int64, flat source row indices computed on the device by the caller (no host loop, no sync). */
 int mmu_gather_rows_bf16(const void* src, const long long* rows, void* dst, long long n_src_rows, int n_dst_rows, int V,
                          void* stream);
+/* Supervised-row selection in front of the lm_head (K13/K14: HF's shifted CE ignores every position whose next label is
+ * -100, mm/dataset.py:325-339 masks image + question tokens, so only the selected hidden-state rows reach the head):
+ * mmu_gather_rows_bf16 with rows[r] < 0 writes a zero row (padding slot); mmu_scatter_rows_bf16 is the backward,
+ * dst[rows[r]][:] = src[r][:] for rows[r] >= 0 (distinct rows; the caller zeroes dst first). */
+int mmu_scatter_rows_bf16(const void* src, const long long* rows, void* dst, long long n_dst_rows, int n_src_rows, int V,
+                          void* stream);
 
 /* Evaluation truth-ratio pass (mm/eval.py:46-92 eval_perturbation_ratio: get_batch_loss + token counts) for n_seq
  * sequences of S rows in one call: out[seq] = {sum_t shifted CE, #shifted targets != -100, #labels != -100 (unshifted:

@@ -1117,12 +1117,38 @@ namespace {
 __global__ __launch_bounds__(256) void gather_rows_kernel(const bf16* __restrict__ src, const long long* __restrict__ rows,
                                                           bf16* __restrict__ dst, int V8, long long n_src_rows) {
     const long long r = rows[blockIdx.x];
-    if (r < 0 || r >= n_src_rows) return;  // never true for indices built by remove_image_tokens; keeps a bad index in bounds
-    const bf16* s = src + (size_t)r * V8 * 8;
+    if (r >= n_src_rows) return;  // never true for indices built by the callers; keeps a bad index in bounds
     bf16* d = dst + (size_t)blockIdx.x * V8 * 8;
+    if (r < 0) {  // padding slot of a fixed-capacity row list (supervised-row selection): a zero row
+        bf16x8 z;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) z[j] = f2bf(0.f);
+        for (int c = threadIdx.x; c < V8; c += 256) *reinterpret_cast<bf16x8*>(d + c * 8) = z;
+        return;
+    }
+    const bf16* s = src + (size_t)r * V8 * 8;
+    for (int c = threadIdx.x; c < V8; c += 256) *reinterpret_cast<bf16x8*>(d + c * 8) = *reinterpret_cast<const bf16x8*>(s + c * 8);
+}
+// dst[rows[r]][:] = src[r][:] for rows[r] >= 0 (the inverse of the gather for a list of DISTINCT rows: the gradient of the
+// selected hidden-state rows back into the [tokens, d] gradient, whose other rows the caller zeroed)
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const bf16* __restrict__ src, const long long* __restrict__ rows,
+                                                           bf16* __restrict__ dst, int V8, long long n_dst_rows) {
+    const long long r = rows[blockIdx.x];
+    if (r < 0 || r >= n_dst_rows) return;
+    const bf16* s = src + (size_t)blockIdx.x * V8 * 8;
+    bf16* d = dst + (size_t)r * V8 * 8;
     for (int c = threadIdx.x; c < V8; c += 256) *reinterpret_cast<bf16x8*>(d + c * 8) = *reinterpret_cast<const bf16x8*>(s + c * 8);
 }
 }  // namespace
+extern "C" int mmu_scatter_rows_bf16(const void* src, const long long* rows, void* dst, long long n_dst_rows, int n_src_rows,
+                                     int V, void* stream) {
+    if (n_src_rows <= 0 || n_dst_rows <= 0 || V <= 0 || (V & 7) || !rows) return -1;
+    if (((uintptr_t)src | (uintptr_t)dst) & 15) return -1;
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(n_src_rows), dim3(256), 0, (hipStream_t)stream, (const bf16*)src, rows,
+                       (bf16*)dst, V >> 3, n_dst_rows);
+    MMU_CHECK_LAUNCH();
+    return 0;
+}
 extern "C" int mmu_gather_rows_bf16(const void* src, const long long* rows, void* dst, long long n_src_rows, int n_dst_rows,
                                     int V, void* stream) {
     if (n_src_rows <= 0 || n_dst_rows <= 0 || V <= 0 || (V & 7) || !rows) return -1;

@@ -74,6 +74,7 @@ SIGNATURES = {
     "mmu_rowloss_fwd": [_i, _vp, _vp, _i, _f, _vp, _i, _i, _vp],
     "mmu_rowloss_bwd": [_i, _vp, _vp, _i, _f, _vp, _vp, _vp, _i, _i, _i, _vp],
     "mmu_gather_rows_bf16": [_vp, _vp, _vp, _ll, _i, _i, _vp],
+    "mmu_scatter_rows_bf16": [_vp, _vp, _vp, _ll, _i, _i, _vp],
     "mmu_rowloss_set_streaming": [_i],
     "mmu_seq_ce_stats": [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "mmu_red_scratch_floats": [],
@@ -528,6 +529,16 @@ def gather_rows(src2d, rows, dst2d):
     assert rows.numel() == dst2d.shape[0] and src2d.shape[1] == dst2d.shape[1]
     _check(load().mmu_gather_rows_bf16(_p(src2d), _p(rows), _p(dst2d), src2d.shape[0], dst2d.shape[0], src2d.shape[1],
                                        _stream()), "mmu_gather_rows_bf16")
+    return dst2d
+
+
+def scatter_rows(src2d, rows, dst2d):
+    """dst2d[rows[r]] = src2d[r] for rows[r] >= 0 (distinct rows; negative = padding slot, skipped)."""
+    _bf16c(src2d, dst2d)
+    assert src2d.is_contiguous() and dst2d.is_contiguous() and rows.dtype == torch.int64 and rows.is_cuda and rows.is_contiguous()
+    assert rows.numel() == src2d.shape[0] and src2d.shape[1] == dst2d.shape[1]
+    _check(load().mmu_scatter_rows_bf16(_p(src2d), _p(rows), _p(dst2d), dst2d.shape[0], src2d.shape[0], src2d.shape[1],
+                                        _stream()), "mmu_scatter_rows_bf16")
     return dst2d
 
 

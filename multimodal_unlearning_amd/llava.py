@@ -80,27 +80,29 @@ class _SegCE(torch.autograd.Function):
     normalize=False, as get_batch_loss needs).  logits2d [M,V] bf16, labels [M] int64 (unshifted), S = seq len."""
 
     @staticmethod
-    def forward(ctx, logits2d, labels, S, seg_rows, normalize):
+    def forward(ctx, logits2d, labels, S, seg_rows, normalize, shift=True, grad_in_place=False):
         M, V = logits2d.shape
         dev = logits2d.device
         lse = torch.empty(M, device=dev, dtype=torch.float32)
         lrow = torch.empty(M, device=dev, dtype=torch.float32)
-        hip.ce_fwd(logits2d, labels, lse, lrow, S, shift=True)
+        hip.ce_fwd(logits2d, labels, lse, lrow, S, shift=shift)
         nseg = (M + seg_rows - 1) // seg_rows
         sums = torch.empty(nseg, device=dev, dtype=torch.float32)
         cnts = torch.empty(nseg, device=dev, dtype=torch.float32)
-        hip.seg_reduce(lrow, labels, seg_rows, M, V, S, True, sums, cnts)
+        hip.seg_reduce(lrow, labels, seg_rows, M, V, S, shift, sums, cnts)
         ctx.save_for_backward(logits2d, labels, lse, cnts)
-        ctx.meta = (S, seg_rows, normalize)
+        ctx.meta = (S, seg_rows, normalize, shift, grad_in_place)
         return sums / cnts.clamp(min=1.0) if normalize else sums
 
     @staticmethod
     def backward(ctx, g):
         logits2d, labels, lse, cnts = ctx.saved_tensors
-        S, seg_rows, normalize = ctx.meta
-        dl = torch.empty_like(logits2d)
-        hip.ce_bwd(logits2d, labels, lse, g.contiguous().float(), cnts, seg_rows, normalize, dl, S, shift=True)
-        return dl, None, None, None, None
+        S, seg_rows, normalize, shift, grad_in_place = ctx.meta
+        # the logits of a loss-only forward belong to this edge alone: their gradient overwrites them in place (the
+        # kernel reads every element before the same lane writes it) instead of taking another [rows, V] buffer
+        dl = logits2d if grad_in_place else torch.empty_like(logits2d)
+        hip.ce_bwd(logits2d, labels, lse, g.contiguous().float(), cnts, seg_rows, normalize, dl, S, shift=shift)
+        return dl, None, None, None, None, None, None
 
 
 class _RowLoss(torch.autograd.Function):
@@ -126,6 +128,30 @@ class _RowLoss(torch.autograd.Function):
         dl = torch.empty_like(slog)
         hip.rowloss_bwd(mode, slog, tlog, beta, stats, g.reshape(1).float().contiguous(), dl)
         return dl, None, None, None
+
+
+def supervised_rows(labels: torch.Tensor, vocab: int, device):
+    """Row selection for a loss-only forward.  HF's causal-LM loss pairs position s with labels[s + 1] and ignores a pair
+    whose label is -100 (the collator masks padding, image and question tokens, mm/dataset.py:325-339), so only the
+    hidden states of the supervised positions ever reach the lm_head.  Returns (rows [B * cap] int64 device: flat row
+    b * S + s per kept position, -1 in the padding slots; labels_c [B * cap] int64 device: the UNshifted target of every
+    slot, -100 in the padding slots; cap = slots per sequence, a multiple of 8).  The index arithmetic runs where the
+    labels live: on the host for collator output (no device sync), on the device otherwise (one sync for `cap`)."""
+    B, S = labels.shape
+    lab = labels.to(torch.int64)
+    valid = (lab[:, 1:] >= 0) & (lab[:, 1:] < vocab)                       # position s < S - 1 predicts lab[s + 1]
+    cnt = valid.sum(dim=1)
+    cap = max(8, (int(cnt.max()) + 7) // 8 * 8) if B else 8
+    cap = min(cap, (S - 1 + 7) // 8 * 8)
+    order = torch.argsort(valid.to(torch.int8), dim=1, descending=True, stable=True)   # kept positions first, in order
+    if order.shape[1] < cap:
+        order = torch.cat([order, order.new_zeros(B, cap - order.shape[1])], dim=1)
+    order = order[:, :cap]
+    live = torch.arange(cap, device=lab.device).unsqueeze(0) < cnt.unsqueeze(1)
+    base = (torch.arange(B, device=lab.device) * S).unsqueeze(1)
+    rows = torch.where(live, base + order, torch.full_like(order, -1))
+    tgt = torch.where(live, torch.gather(lab, 1, (order + 1).clamp(max=S - 1)), torch.full_like(order, -100))
+    return rows.reshape(-1).contiguous().to(device), tgt.reshape(-1).contiguous().to(device), cap
 
 
 def causal_lm_loss(logits, labels):
@@ -238,6 +264,7 @@ class LlavaHIP(nn.Module):
         # engine then reduces what no hook covered).
         self.live_sweeps = 0
         self.capture_layer: Optional[int] = None
+        self._rows_cache: list = []
         self.position_ids_mode = "arange"  # or "from_mask" (transformers 4.45.1 left-padding positions); see _positions
         if self.lora:
             self.init_lora_(seed)
@@ -561,8 +588,58 @@ class LlavaHIP(nn.Module):
         return self._grad_flat
 
     # ----------------------------------------------------------------------------------------- forward
+    # model(**split, loss_only=True) is understood (the plug-in asks before passing the keyword to a foreign model)
+    supports_loss_only = True
+
+    def ce_losses(self, input_ids, attention_mask=None, pixel_values=None, labels=None, position_ids=None,
+                  n_segments: int = 1):
+        """HF's causal-LM loss of the batch — per segment when the batch concatenates `n_segments` equal splits (paired
+        forget / retain fusion) — WITHOUT the logits of positions that carry no loss: the final norm, the lm_head GEMM,
+        the CE kernels and their backward run on the supervised rows only (`supervised_rows`).  Same value and gradients
+        as `forward(...).loss` up to summation order (tests/test_model_gpu.py::test_loss_only_matches_full_logits); at
+        the headline workload 256 of 1088 positions per sequence are supervised: -76 % of the lm_head's three GEMMs."""
+        dev = self.device
+        ids = input_ids.to(dev, dtype=torch.int64).contiguous()
+        B, S = ids.shape
+        assert B % n_segments == 0
+        # device-resident label tensors that are stepped over repeatedly (bench.py) pay the sync of the row selection
+        # once: the cache holds the tensor OBJECT (so its memory cannot be recycled under the entry) and its version
+        hit = None
+        for t_, ver, val in self._rows_cache:
+            if t_ is labels and ver == labels._version:
+                hit = val
+                break
+        if hit is None:
+            hit = supervised_rows(labels, self.cfg.text.vocab_size, dev)
+            if labels.is_cuda:
+                self._rows_cache.append((labels, labels._version, hit))
+                del self._rows_cache[:-16]
+        rows, tgt, cap = hit
+        kmask = self._kmask(attention_mask)
+        pos = self._positions(position_ids, attention_mask, B, S)
+        pix = None
+        if pixel_values is not None and pixel_values.numel() > 0:
+            pix = pixel_values.to(dev, dtype=torch.float32).contiguous()
+        if torch.is_grad_enabled() and self.train_flat.requires_grad:
+            lc = _LlavaFn.apply(self.train_flat, self, ids, kmask, pix, pos, None, rows)
+        else:
+            with torch.no_grad():
+                lc, _ = self._forward_impl(ids, kmask, pix, pos, save=False, rows=rows)
+        return _SegCE.apply(lc, tgt, cap, (B // n_segments) * cap, True, False, True)
+
+    def _kmask(self, attention_mask):
+        if attention_mask is None:
+            return None
+        # host-resident masks (collator output) are checked for padding without a device sync
+        if attention_mask.device.type == "cpu":
+            return None if bool(attention_mask.all()) else attention_mask.to(self.device, dtype=torch.int32).contiguous()
+        return attention_mask.to(dtype=torch.int32).contiguous()
+
     def forward(self, input_ids=None, attention_mask=None, pixel_values=None, labels=None, position_ids=None,
-                **_unused):
+                loss_only: bool = False, **_unused):
+        if loss_only and labels is not None and self.capture_layer is None:
+            loss = self.ce_losses(input_ids, attention_mask, pixel_values, labels, position_ids)[0]
+            return LlavaOutput(loss=loss, logits=None)
         logits = self.logits(input_ids, attention_mask, pixel_values, position_ids)
         loss = None
         if labels is not None:
@@ -592,14 +669,7 @@ class LlavaHIP(nn.Module):
 
     def logits(self, input_ids, attention_mask=None, pixel_values=None, position_ids=None):
         dev = self.device
-        kmask = None
-        if attention_mask is not None:
-            # host-resident masks (collator output) are checked for padding without a device sync
-            if attention_mask.device.type == "cpu":
-                if not bool(attention_mask.all()):
-                    kmask = attention_mask.to(dev, dtype=torch.int32).contiguous()
-            else:
-                kmask = attention_mask.to(dtype=torch.int32).contiguous()
+        kmask = self._kmask(attention_mask)
         ids = input_ids.to(dev, dtype=torch.int64).contiguous()
         B, S = ids.shape
         pos = self._positions(position_ids, attention_mask, B, S)
@@ -738,7 +808,8 @@ class LlavaHIP(nn.Module):
             out, _ = self._forward_impl(ids, kmask, pix, pos, save=False, stop_layer=layer)
         return out
 
-    def _forward_impl(self, ids, kmask, pix, pos, save: bool, stop_layer: Optional[int] = None):
+    def _forward_impl(self, ids, kmask, pix, pos, save: bool, stop_layer: Optional[int] = None,
+                      rows: Optional[torch.Tensor] = None):
         cfg, t, w = self.cfg, self.cfg.text, self.w
         dev = self.device
         B, S = ids.shape
@@ -795,6 +866,23 @@ class LlavaHIP(nn.Module):
             if stop_layer is not None and i == stop_layer:
                 self._fwd_U = None
                 return h.view(B, S, dt), saved
+        if rows is not None:
+            # loss-only forward: final norm + lm_head on the supervised rows only (padding slots are zero rows, their
+            # targets are -100); returns the compact logits [len(rows), V]
+            Mc = rows.numel()
+            hc = torch.empty(Mc, dt, device=dev, dtype=BF)
+            hip.gather_rows(h, rows, hc)
+            del h
+            rstdf = torch.empty(Mc, device=dev, dtype=torch.float32)
+            yc = y[:Mc] if Mc <= M else torch.empty(Mc, dt, device=dev, dtype=BF)
+            hip.rmsnorm_fwd(hc, w["text.norm.weight"], yc, rstdf, t.rms_norm_eps)
+            logits = torch.empty(Mc, t.vocab_size, device=dev, dtype=BF)
+            self._lin_fwd("lm_head.weight", yc, logits)
+            if save:
+                saved["final"] = (hc, rstdf)
+                saved["rows"] = rows
+            self._fwd_U = None
+            return logits, saved
         rstdf = torch.empty(M, device=dev, dtype=torch.float32)
         hip.rmsnorm_fwd(h, w["text.norm.weight"], y, rstdf, t.rms_norm_eps)
         logits = torch.empty(M, t.vocab_size, device=dev, dtype=BF)
@@ -815,7 +903,9 @@ class LlavaHIP(nn.Module):
         M = B * S
         dt, I, H, D, V = t.hidden_size, t.intermediate_size, t.num_heads, t.head_dim, t.vocab_size
         scale = D ** -0.5
-        dlog = dlogits.reshape(M, -1)
+        rows = saved.get("rows")
+        Mh = rows.numel() if rows is not None else M   # rows that went through the final norm and the lm_head
+        dlog = dlogits.reshape(Mh, -1)
         if not dlog.is_contiguous():
             dlog = dlog.contiguous()
         if dlog.dtype != BF:
@@ -829,7 +919,31 @@ class LlavaHIP(nn.Module):
         dy = torch.empty(M, dt, device=dev, dtype=BF)
         use_t = self._use_t(M)
         yT = torch.empty(dt, M, device=dev, dtype=BF) if use_t else None
-        if stop_layer is None:
+        if stop_layer is None and rows is not None:
+            # loss-only forward: the head ran on the supervised rows; their hidden-state gradients are scattered back
+            # into a zero [tokens, d] gradient (every other position reaches the loss through attention only)
+            hc, rstdf = saved["final"]
+            dyc = torch.empty(Mh, dt, device=dev, dtype=BF)
+            if self._use_t(Mh):
+                ycT = torch.empty(dt, Mh, device=dev, dtype=BF)
+                hip.rmsnorm_apply_t(hc, w["text.norm.weight"], rstdf, ycT)
+                self._wgrad_t(dlog, None, ycT, "lm_head.weight")
+                self._dgrad(dlog, "lm_head.weight", dyc)
+                del ycT
+            else:
+                yc = torch.empty(Mh, dt, device=dev, dtype=BF)
+                hip.rmsnorm_fwd(hc, w["text.norm.weight"], yc, None, t.rms_norm_eps)
+                self._lin_bwd("lm_head.weight", dlog, yc, dyc)
+                del yc
+            dhc = torch.empty(Mh, dt, device=dev, dtype=BF)
+            dwp = dw_part if hip.rmsnorm_bwd_nparts(Mh) <= npart else torch.empty(hip.rmsnorm_bwd_nparts(Mh) * dt, device=dev,
+                                                                                  dtype=torch.float32)
+            hip.rmsnorm_bwd(dyc, hc, w["text.norm.weight"], rstdf, None, dhc, dwp, g.get("text.norm.weight"), True)
+            dh = torch.zeros(M, dt, device=dev, dtype=BF)
+            hip.scatter_rows(dhc, rows, dh)
+            del dyc, dhc, hc
+            top = t.num_layers - 1
+        elif stop_layer is None:
             h, rstdf = saved["final"]
             if use_t:
                 hip.rmsnorm_apply_t(h, w["text.norm.weight"], rstdf, yT)
@@ -956,8 +1070,8 @@ class _LlavaFn(torch.autograd.Function):
     into the model's flat gradient buffer (train_flat.grad) and returns no tensor for it."""
 
     @staticmethod
-    def forward(ctx, train_flat, model: LlavaHIP, ids, kmask, pix, pos, stop_layer=None):
-        logits, saved = model._forward_impl(ids, kmask, pix, pos, save=True, stop_layer=stop_layer)
+    def forward(ctx, train_flat, model: LlavaHIP, ids, kmask, pix, pos, stop_layer=None, rows=None):
+        logits, saved = model._forward_impl(ids, kmask, pix, pos, save=True, stop_layer=stop_layer, rows=rows)
         model.live_sweeps += 1
         ctx.model = model
         ctx.saved = saved
@@ -969,4 +1083,4 @@ class _LlavaFn(torch.autograd.Function):
         ctx.saved = None
         model.live_sweeps = max(0, model.live_sweeps - 1)
         model._backward_impl(saved, dlogits, fire_hooks=model.live_sweeps == 0)
-        return None, None, None, None, None, None, None
+        return None, None, None, None, None, None, None, None

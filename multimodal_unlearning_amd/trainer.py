@@ -127,6 +127,8 @@ class MMTrainerForgetting:
         if self.l1_lambda and self.l1_lambda != 0 and self.l_norm_from not in ("zero", "init"):
             raise ValueError(f"Invalid l_norm_from {self.l_norm_from}, should be 'zero' or 'init'")
         self.fuse_pairs = bool(self.loss_args.get("fuse_pairs", True))
+        # MI355X addition: forwards of which only `.loss` is read run the lm_head on the supervised rows (A/B switch)
+        self.loss_only_head = bool(self.loss_args.get("loss_only_head", True))
         self.control_vec = None
         self.is_deepspeed_enabled = False
         if tu.loss_needs_teacher(self.loss_type) and self.teacher_model is None:
@@ -162,13 +164,26 @@ class MMTrainerForgetting:
             return False
         return pa is None or pa.shape[1:] == pb.shape[1:]
 
-    def _paired_ce(self, model, a, b):
-        """One forward over cat(a, b); returns (ce_a, ce_b, outputs)."""
+    def _paired_ce(self, model, a, b, need_outputs=False):
+        """One forward over cat(a, b); returns (ce_a, ce_b, outputs).  When nobody asked for the outputs and the model
+        can do it, the head runs on the supervised rows only (LlavaHIP.ce_losses) and `outputs` carries no logits."""
         cat = {k: torch.cat([a[k], b[k]], dim=0) for k in _SPLIT_KEYS if k in a and k != "labels"}
+        labels = torch.cat([a["labels"], b["labels"]], dim=0)
+        if not need_outputs and getattr(model, "supports_loss_only", False) and self.loss_only_head:
+            ce = model.ce_losses(labels=labels, n_segments=2, **cat)
+            from .llava import LlavaOutput
+            return ce[0], ce[1], LlavaOutput(loss=None, logits=None)
         out = model(**cat)
-        labels = torch.cat([a["labels"], b["labels"]], dim=0).to(out.logits.device)
-        ce = segment_ce_losses(out.logits, labels, 2)
+        ce = segment_ce_losses(out.logits, labels.to(out.logits.device), 2)
         return ce[0], ce[1], out
+
+    def _loss_of(self, model, split, need_outputs=False):
+        """`model(**split)` when only `.loss` will be read: models that understand `loss_only=True` (LlavaHIP) skip the
+        logits of unsupervised positions; `need_outputs` (the caller returns the outputs) or a foreign model keep the
+        full forward."""
+        if not need_outputs and getattr(model, "supports_loss_only", False) and self.loss_only_head and "labels" in split:
+            return model(**split, loss_only=True)
+        return model(**split)
 
     def compute_loss(self, model, inputs, return_outputs=False, *args, **kwargs):
         dev = next(model.parameters()).device
@@ -179,21 +194,24 @@ class MMTrainerForgetting:
         random_inputs = td(dev, inputs["random"]) if "random" in inputs else None
         lt, beta = self.loss_type, self.loss_beta
         outputs = None
+        # does anybody read the outputs?  (the text trainer calls this method with return_outputs=True for its own
+        # bookkeeping and passes what ITS caller asked for in `_need_outputs`)
+        need_out = bool(kwargs.get("_need_outputs", return_outputs))
 
         if lt == "retain_ft":
-            outputs = model(**retain_inputs)
+            outputs = self._loss_of(model, retain_inputs, need_out)
             loss = outputs.loss
 
         elif lt == "grad_ascent":
-            outputs = model(**forget_inputs)
+            outputs = self._loss_of(model, forget_inputs, need_out)
             loss = -1 * outputs.loss
 
         elif lt.startswith("grad_diff"):
             if "forget_ce" in lt and "retain_ce" in lt and self.fuse_pairs and self._can_fuse(forget_inputs, retain_inputs):
-                forget_loss, retain_loss, outputs = self._paired_ce(model, forget_inputs, retain_inputs)
+                forget_loss, retain_loss, outputs = self._paired_ce(model, forget_inputs, retain_inputs, need_out)
             else:
-                forget_outputs = model(**forget_inputs)
-                retain_outputs = model(**retain_inputs)
+                forget_outputs = self._loss_of(model, forget_inputs, "forget_ce" not in lt)
+                retain_outputs = self._loss_of(model, retain_inputs, need_out or "retain_ce" not in lt)
                 outputs = retain_outputs
                 if "forget_ce" in lt:
                     forget_loss = forget_outputs.loss
@@ -224,7 +242,7 @@ class MMTrainerForgetting:
             outputs = retain_outputs
 
         elif lt == "kl":
-            forget_outputs = model(**forget_inputs)
+            forget_outputs = self._loss_of(model, forget_inputs)
             forget_loss = -1 * forget_outputs.loss
             oracle_r = self._teacher(retain_inputs)
             retain_outputs = model(**retain_inputs)
@@ -233,8 +251,8 @@ class MMTrainerForgetting:
             outputs = retain_outputs
 
         elif lt == "llmu":
-            forget_loss = -1 * model(**forget_inputs).loss
-            random_loss = model(**idk_inputs).loss
+            forget_loss = -1 * self._loss_of(model, forget_inputs).loss
+            random_loss = self._loss_of(model, idk_inputs).loss
             retain_outputs = model(**retain_inputs)
             oracle_r = self._teacher(retain_inputs)
             retain_loss = tu.kl_div_batchmean(oracle_r.logits, retain_outputs.logits, student_is_input=False)
@@ -248,20 +266,20 @@ class MMTrainerForgetting:
 
         elif lt == "idk":
             if self.fuse_pairs and self._can_fuse(retain_inputs, idk_inputs):
-                a, b, outputs = self._paired_ce(model, retain_inputs, idk_inputs)
+                a, b, outputs = self._paired_ce(model, retain_inputs, idk_inputs, need_out)
                 loss = a + b
             else:
-                retain_outputs = model(**retain_inputs)
-                outputs = model(**idk_inputs)
+                retain_outputs = self._loss_of(model, retain_inputs)
+                outputs = self._loss_of(model, idk_inputs, need_out)
                 loss = retain_outputs.loss + outputs.loss
 
         elif lt == "eco_ft":
             if self.fuse_pairs and self._can_fuse(forget_inputs, retain_inputs):
-                a, b, outputs = self._paired_ce(model, forget_inputs, retain_inputs)
+                a, b, outputs = self._paired_ce(model, forget_inputs, retain_inputs, need_out)
                 loss = beta * a + b
             else:
-                forget_outputs = model(**forget_inputs)
-                outputs = model(**retain_inputs)
+                forget_outputs = self._loss_of(model, forget_inputs)
+                outputs = self._loss_of(model, retain_inputs, need_out)
                 loss = beta * forget_outputs.loss + outputs.loss
 
         elif lt == "dpo":
@@ -280,12 +298,12 @@ class MMTrainerForgetting:
             loss = -idk_loss_current.mean()
 
         elif lt == "sku":
-            bad_loss = model(**forget_inputs).loss
+            bad_loss = self._loss_of(model, forget_inputs).loss
             # [B, K, ...] -> K batches; the reference transposes in place (mm/trainer.py:420-421); we do not mutate
             K = random_inputs["input_ids"].shape[1]
             random_loss = 0.0
             for i in range(K):
-                random_loss = random_loss + model(**{k: v[:, i] for k, v in random_inputs.items()}).loss
+                random_loss = random_loss + self._loss_of(model, {k: v[:, i] for k, v in random_inputs.items()}).loss
             oracle_r = self._teacher(retain_inputs)
             outputs = model(**retain_inputs)
             normal_loss = -1 * tu.kl_div_batchmean(outputs.logits, oracle_r.logits, student_is_input=True)
@@ -410,7 +428,7 @@ class CustomTrainerForgetting(MMTrainerForgetting):
             loss = 2 / beta * row_loss_sum(outputs.logits, oracle.logits, hip.NPO_NLP, beta) / n
         elif lt == "idk":
             cat = {k: torch.cat((f[k], r[k]), dim=0) for k in ("input_ids", "attention_mask", "labels")}
-            outputs = model(**cat)
+            outputs = self._loss_of(model, cat, return_outputs)
             loss = outputs.loss
         elif lt == "RMU":
             layer = int(self.loss_args.get("rmu_layer", 7))
@@ -431,7 +449,8 @@ class CustomTrainerForgetting(MMTrainerForgetting):
             try:
                 if lt.startswith("grad_diff") and "forget_ce" not in lt and "forget_entropy" not in lt and "forget_KL" not in lt:
                     raise ValueError(f"Invalid loss type on forget {lt}")
-                res = MMTrainerForgetting.compute_loss(self, model, nested, return_outputs=True, _skip_reg=True)
+                res = MMTrainerForgetting.compute_loss(self, model, nested, return_outputs=True, _skip_reg=True,
+                                                       _need_outputs=return_outputs)
             finally:
                 self.loss_type = keep
             loss, outputs = res

@@ -150,6 +150,41 @@ def test_paired_fusion_is_equivalent(models):
     assert _relerr(res[True][1], res[False][1]) < 1e-2
 
 
+@pytest.mark.parametrize("lt", ["grad_diff_forget_ce_retain_ce", "grad_ascent", "KL", "idk", "llmu"])
+def test_loss_only_matches_full_logits(models, lt):
+    """Forwards of which only `.loss` is read run the final norm + lm_head + CE on the supervised rows only
+    (LlavaHIP.ce_losses).  Same loss and gradients as the full-logits forward: every supervised row goes through the same
+    kernels with the same operands; only the order of the CE sum and of the wgrad accumulation differs.  Ragged batch:
+    left padding, a different number of supervised tokens per sequence, labels on the host and on the device."""
+    from multimodal_unlearning_amd.trainer import MMTrainerForgetting
+
+    cfg, P, student, teacher = models
+    inputs = make_forget_batch(cfg, 3, 40, seed=15, n_question=7, splits=("forget", "retain", "idk"))
+    for name, sp in inputs.items():  # ragged supervision + left padding on one sequence
+        sp["labels"][1, :25] = -100
+        sp["labels"][2, 30:] = -100
+        sp["attention_mask"][0, :3] = 0
+        sp["labels"][0, :3] = -100
+    res = {}
+    for mode in ("full", "rows_host_labels", "rows_device_labels"):
+        tr = MMTrainerForgetting(model=student, forget_loss=lt, teacher_model=teacher, loss_beta=1.3, l1_lambda=0,
+                                 l0_lambda=0, l_norm_from="zero", loss_args={"loss_only_head": mode != "full"})
+        x = inputs if mode != "rows_device_labels" else {k: {a: b.to(student.device) for a, b in v.items()} for k, v in inputs.items()}
+        student.ensure_grad().zero_()
+        loss = tr.compute_loss(student, x)
+        loss.backward()
+        res[mode] = (loss.item(), student.ensure_grad().clone())
+    for mode in ("rows_host_labels", "rows_device_labels"):
+        assert abs(res[mode][0] - res["full"][0]) < 2e-6 * max(1, abs(res["full"][0])), (mode, res[mode][0], res["full"][0])
+        assert _relerr(res[mode][1], res["full"][1]) < 5e-3, (mode, _relerr(res[mode][1], res["full"][1]))
+    # return_outputs=True keeps the full forward (somebody reads the logits)
+    tr = MMTrainerForgetting(model=student, forget_loss="grad_ascent", teacher_model=None, loss_beta=1.0, l1_lambda=0,
+                             l0_lambda=0, l_norm_from="zero")
+    loss, out = tr.compute_loss(student, inputs, return_outputs=True)
+    assert out.logits is not None and out.logits.shape[:2] == inputs["forget"]["input_ids"].shape
+    assert tr.compute_loss(student, inputs, return_outputs=False).item() == pytest.approx(loss.item(), rel=2e-6)
+
+
 def test_transposed_weight_dgrad_matches(models):
     """dgrad through the resident W^T copies (NT path) == dgrad through W (NN path)."""
     from multimodal_unlearning_amd.trainer import MMTrainerForgetting
