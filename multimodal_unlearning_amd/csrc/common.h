@@ -39,8 +39,13 @@ __device__ __forceinline__ bf16 f2bf(float x) { return (bf16)x; }  // v_cvt_pk_b
 __device__ __forceinline__ float round_bf16(float x) { return bf2f((bf16)x); }
 
 // async global -> LDS, 16 B per lane; LDS destination = wave-uniform base + lane*16.
+// MMU_GLDS_AUX: cache-policy bits of the load (A/B builds only; sc0 = 1, nt = 2, sc1 = 16; measured on the GEMM,
+// profiles/r03_glds_cache_policy_ab.txt: the default policy is the fastest)
+#ifndef MMU_GLDS_AUX
+#define MMU_GLDS_AUX 0
+#endif
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const MMU_GLOBAL void*)gsrc, (MMU_LDS void*)lds_wave_base, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const MMU_GLOBAL void*)gsrc, (MMU_LDS void*)lds_wave_base, 16, 0, MMU_GLDS_AUX);
 }
 
 // async global -> LDS, 4 B per lane; LDS destination = wave-uniform base + lane*4.
