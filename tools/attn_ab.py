@@ -1,6 +1,6 @@
 """A/B of two builds of libmmu_hip.so on the attention kernels at the 7B step's shape (B x 32 heads x S 1088 x D 128,
 causal), interleaved rounds in ONE process (guide rule 24), plus a cross-check of the outputs.
-Usage: python tools/attn_ab.py LIB_A LIB_B [B]"""
+Usage: python tools/attn_ab.py LIB_A LIB_B [B] [mask]"""
 import ctypes as C, math, os, statistics, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -16,6 +16,7 @@ for tag, spec in (("A", la), ("B", lb)):
     if tag == "A": la = spec
     else: lb = spec
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 30
+ONES_MASK = len(sys.argv) > 4 and sys.argv[4] == "mask"  # a device-resident all-ones key mask, as the step passes
 H, S, D = 32, 1088, 128
 dev = torch.device("cuda:0")
 libs = {}
@@ -31,6 +32,8 @@ HD = H * D
 qkv = torch.randn(B * S, 3 * HD, device=dev, generator=g).bfloat16()
 do = torch.randn(B * S, HD, device=dev, generator=g).bfloat16()
 sc = 1 / math.sqrt(D)
+kmask = torch.ones(B, S, device=dev, dtype=torch.int32)
+KM = kmask.data_ptr() if ONES_MASK else 0
 st = lambda: torch.cuda.current_stream().cuda_stream
 out = {}
 for tag in libs:
@@ -39,14 +42,14 @@ for tag in libs:
 p = lambda t: t.data_ptr()
 def fwd(tag):
     o = out[tag]
-    rc = libs[tag].mmu_attn_fwd(p(qkv), p(qkv) + 2 * HD, p(qkv) + 4 * HD, 3 * HD, p(o["o"]), HD, p(o["lse"]), 0, B, S, H, D, sc, 1, st())
+    rc = libs[tag].mmu_attn_fwd(p(qkv), p(qkv) + 2 * HD, p(qkv) + 4 * HD, 3 * HD, p(o["o"]), HD, p(o["lse"]), KM, B, S, H, D, sc, 1, st())
     assert rc == 0, rc
 def bwd(tag):
     o = out[tag]
     if tag in var:
         assert libs[tag].mmu_attn_set_dkdv_variant(var[tag]) == 0
     d = o["dqkv"]
-    rc = libs[tag].mmu_attn_bwd_rope(p(qkv), p(qkv) + 2 * HD, p(qkv) + 4 * HD, 3 * HD, p(o["o"]), HD, p(o["lse"]), 0, p(do), HD,
+    rc = libs[tag].mmu_attn_bwd_rope(p(qkv), p(qkv) + 2 * HD, p(qkv) + 4 * HD, 3 * HD, p(o["o"]), HD, p(o["lse"]), KM, p(do), HD,
                                      p(o["delta"]), p(d), p(d) + 2 * HD, p(d) + 4 * HD, 3 * HD, B, S, H, D, sc, 1, 0, 0, 0, st())
     assert rc == 0, rc
 def timed(fn, tag, n=5):
