@@ -75,14 +75,24 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     RowStager<D, KIND_TR, 64> st_v;
     st_k.init(a.ld, wave, lane);
     st_v.init(a.ld, wave, lane);
+    // The staging wave fetches the key-mask word of a block ONE stage call ahead, and before that call's LDS-DMA: loaded
+    // at its point of use, the word's s_waitcnt vmcnt(0) also waited for the DMA just issued (vmcnt retires in order), a
+    // full memory latency in front of every block of a padded batch (565 vs 502 us, profiles/r03_attn_fwd8_experiment.txt).
+    auto load_mask = [&](int kb) -> int {
+        const int key = kb * 64 + (int)threadIdx.x;
+        return (threadIdx.x < 64 && a.kmask != nullptr && key < S) ? a.kmask[rowbase + key] : 1;
+    };
+    int mk_pre = load_mask(0);
     auto stage = [&](int kb, int buf) {
         char* base = smem + buf * 2 * TB;
+        const int mk = mk_pre;
+        mk_pre = load_mask(kb + 1);
         st_k.issue(base, kp, a.ld, kb * 64, S, wave);
         st_v.issue(base + TB, vp, a.ld, kb * 64, S, wave);
         // the bias row is read by masked blocks only (padding, tail, or the causal diagonal of some wave of this tile)
         if (threadIdx.x < 64 && (a.kmask != nullptr || kb * 64 + 64 > S || (CAUSAL && kb * 64 + 63 > qb * 128))) {
             const int key = kb * 64 + threadIdx.x;
-            const bool ok = key < S && (a.kmask == nullptr || a.kmask[rowbase + key] != 0);
+            const bool ok = key < S && mk != 0;
             kbias[buf * 64 + threadIdx.x] = ok ? 0.f : -INFINITY;
             // a key mask that masks nothing in this block (the step passes device-resident masks it cannot inspect on the
             // host: all ones without padding) must not cost the masked path: wave 0 leaves "all 64 keys valid" here
@@ -348,13 +358,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     // K and V tiles share one set of precomputed per-lane offsets (same row stride, same row-read swizzle)
     RowStager<D, KIND_ROW, 64> st_kv;
     st_kv.init(a.ld, wave, lane);
+    auto load_mask = [&](int kb) -> int {  // one stage call ahead and in front of the LDS-DMA: see attn_fwd_kernel
+        const int key = kb * 64 + (int)threadIdx.x;
+        return (threadIdx.x < 64 && a.kmask != nullptr && key < S) ? a.kmask[rowbase + key] : 1;
+    };
+    int mk_pre = load_mask(0);
     auto stage = [&](int kb, int buf) {
         char* base = smem + buf * 2 * TB;
+        const int mk = mk_pre;
+        mk_pre = load_mask(kb + 1);
         st_kv.issue(base, kp, a.ld, kb * 64, S, wave);
         st_kv.issue(base + TB, vp, a.ld, kb * 64, S, wave);
         if (threadIdx.x < 64) {
             const int key = kb * 64 + threadIdx.x;
-            const bool ok = key < S && (a.kmask == nullptr || a.kmask[rowbase + key] != 0);
+            const bool ok = key < S && mk != 0;
             kbias[buf * 64 + threadIdx.x] = ok ? 0.f : -INFINITY;
             const bool all_ok = __all(ok);  // see attn_fwd_kernel: a mask that masks nothing here takes the plain path
             if (threadIdx.x == 0) kflag[buf] = all_ok ? 1 : 0;
