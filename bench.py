@@ -430,6 +430,10 @@ def main():
             first = mbs[0]
             labs = [sp[1] for sp in first] if args.text_only else [sp["labels"] for sp in first.values()]
             head_rows = sum(supervised_rows(x.cpu(), cfg.text.vocab_size, "cpu")[2] for x in labs) / len(labs)
+        elif not args.full_logits and lt == "kl" and not args.text_only:
+            # forget side: loss-only forward (CE); retain side: full logits for the KL term
+            from multimodal_unlearning_amd.llava import supervised_rows
+            head_rows = (supervised_rows(mbs[0]["forget"]["labels"].cpu(), cfg.text.vocab_size, "cpu")[2] + S) / 2
         fps_alg = flops_per_sample(cfg, S, paired=paired, lora=bool(args.lora_r), text_only=args.text_only)
         fps = flops_per_sample(cfg, S, paired=paired, lora=bool(args.lora_r), text_only=args.text_only, head_rows=head_rows)
         # teacher forwards (no grad): npo 1, kl 1, scrub 2, grad_diff_*_kl 1 per kl side
