@@ -21,6 +21,8 @@
 // Tails (any M, N; K) are zero-filled by redirecting the per-lane source to a 16-B zero page.
 // The MFMA is issued with operands swapped (weight/N fragment as A, token/M fragment as B) so each
 // lane ends up with 4 consecutive n of one output row -> 8-byte bf16x4 stores.
+#include <atomic>
+
 #include "common.h"
 
 struct RopeReq { const int* pos; const bf16* cos; const bf16* sin; int cols; };
@@ -28,7 +30,7 @@ static int g_force_tile = 0;  // mmu_gemm_set_tile
 static int g_group_m = 0;     // mmu_gemm_set_group_m
 static int g_persist = 1;     // mmu_gemm_set_persistent: 0 one workgroup per tile; 1 persistent, tiles drawn from a device-side queue (default); 2 persistent, static walk (A/B)
 static int* g_tileq = nullptr;   // mmu_gemm_set_tile_queue: TQ_SLOTS x 16 zeroed ints (8 per-XCD-class tile counters + 1 exit counter per slot)
-static unsigned g_tileq_seq = 0;  // launches take the slots round-robin, so kernels in flight on different streams never share one
+static std::atomic<unsigned> g_tileq_seq{0};  // launches take the slots round-robin (also from several host threads), so kernels in flight on different streams never share one
 static int g_num_cu = 256;    // MI355X; replaced by the device's own count on the first launch (cu_count())
 static int g_tail_split = 1;     // mmu_gemm_set_tail_split: 0 off, 1 heuristic, 2 whenever the remainder is <= half a round
 static float* g_sk_ws = nullptr;  // mmu_gemm_set_workspace
@@ -914,7 +916,7 @@ int launch_epi(GemmArgs a, hipStream_t stream) {
     // persistent: mode 1 draws tiles from a queue slot (needs mmu_gemm_set_tile_queue; without one it is one workgroup
     // per tile, which shares the GPU gracefully), mode 2 is the static walk
     const bool persist = tiles > g_num_cu && (g_persist == 2 || (g_persist == 1 && g_tileq));
-    if (persist && g_persist == 1) a.tq = g_tileq + (size_t)(g_tileq_seq++ % TQ_SLOTS) * 16;
+    if (persist && g_persist == 1) a.tq = g_tileq + (size_t)(g_tileq_seq.fetch_add(1, std::memory_order_relaxed) % TQ_SLOTS) * 16;
     const int grid = persist ? g_num_cu : tiles;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS_BYTES + 16, stream, a);
     MMU_CHECK_LAUNCH();
