@@ -287,6 +287,11 @@ def main():
     ap.add_argument("--dp-mode", default="allreduce", choices=["allreduce", "rs_ag"],
                     help="gradient exchange at N > 1: bucketed all-reduce overlapped with backward (default), or "
                          "reduce-scatter + sharded AdamW state + parameter all-gather (ZeRO-style, state / N)")
+    ap.add_argument("--squat-workgroups", type=int, default=0,
+                    help="SIMULATION (1 GPU): at the moment the gradient exchange of an N > 1 run would start (first final "
+                         "range of the last micro-batch's backward sweep) park this many 256-thread workgroups on a second "
+                         "stream for --squat-ms, standing in for RCCL's all-reduce kernels (tests/c_abi/squatter.hip)")
+    ap.add_argument("--squat-ms", type=float, default=80.0)
     ap.add_argument("--no-fuse", action="store_true")
     ap.add_argument("--full-logits", action="store_true",
                     help="A/B: every forward materialises all logits (round-2 behaviour); default: forwards of which only "
@@ -348,6 +353,23 @@ def main():
     fcfg = ForgetConfig(batch_size=args.micro_batch, gradient_accumulation_steps=args.grad_accum)
     eng = ForgetEngine(model, tr, fcfg, total_steps=args.steps + args.warmup + 1, warmup_steps=1,
                        transposed_weights=not args.no_wt, optimizer=args.optim, dp_mode=args.dp_mode)
+
+    if args.squat_workgroups:
+        import ctypes
+        import subprocess
+        so = os.path.join(ROOT, "tests", "c_abi", "libsquatter.so")
+        if not os.path.exists(so):
+            subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-shared", "-fPIC", "-o", so,
+                            os.path.join(ROOT, "tests", "c_abi", "squatter.hip")], check=True)
+        sq = ctypes.CDLL(so)
+        sq.squat_launch.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p]
+        sq.squat_launch.restype = ctypes.c_int
+        side = torch.cuda.Stream()
+
+        def squat():  # bounded: at most 1 s per launch (squatter.hip)
+            side.wait_stream(torch.cuda.current_stream())  # it starts when the sweep has reached this point, as RCCL would
+            assert sq.squat_launch(args.squat_workgroups, 256, int(args.squat_ms * 1e5), ctypes.c_void_p(side.cuda_stream)) == 0
+        eng.exchange_start_callback = squat
 
     B, GA = args.micro_batch, args.grad_accum
     n_seq = B * (2 if (len(splits) >= 2 and not args.no_fuse and args.loss.lower() in ("grad_diff_forget_ce_retain_ce", "eco_ft", "idk")) else 1)
@@ -487,6 +509,7 @@ def main():
             "dp": {"mode": args.dp_mode if world > 1 else None, "backend": (dist.get_backend() if world > 1 else None),
                    "gradient_bytes_per_step": model.train_flat.numel() * 2,
                    "exposed_exchange_ms_per_step": [round(x, 2) for x in rank_exch_ms] if world > 1 else None},
+            "simulated_exchange": ({"squatter_workgroups": args.squat_workgroups, "ms": args.squat_ms} if args.squat_workgroups else None),
             "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 1e9, 1),
             # priced with the FLOPs the step EXECUTES (fps); SURVEY §8d's algorithmic count, which charges the lm_head for
             # every position, is reported next to it

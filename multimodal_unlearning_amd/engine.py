@@ -278,8 +278,22 @@ class ForgetEngine:
         # and the completion of the last collective (device events; read by bench.py, never synchronised here)
         self.time_exchange = False
         self.exchange_events = []
+        # measurement hook (bench.py --squat-*): called once per step at the moment the gradient exchange would start,
+        # i.e. when the backward sweep of the last micro-batch reports its first final range
+        self.exchange_start_callback: Optional[Callable[[], None]] = None
         if transposed_weights:
             model.enable_transposed_weights()
+
+    def _with_start_callback(self, hook):
+        fired = []
+
+        def wrapped(lo, hi):
+            if not fired:
+                fired.append(1)
+                self.exchange_start_callback()
+            if hook is not None:
+                hook(lo, hi)
+        return wrapped
 
     def _grad_sumsq(self):
         """|g|^2 over the whole (reduced) gradient into self.sumsq[0], identical on every rank."""
@@ -303,7 +317,10 @@ class ForgetEngine:
         total = None
         for i, mb in enumerate(micro_batches):
             last = i == ga - 1
-            model.grad_ready_hook = self.reducer.mark_final if (last and self.reducer.enabled) else None
+            hook = self.reducer.mark_final if (last and self.reducer.enabled) else None
+            if last and self.exchange_start_callback is not None:
+                hook = self._with_start_callback(hook)
+            model.grad_ready_hook = hook
             model.live_sweeps = 0
             loss = self.trainer.compute_loss(model, mb)
             (loss / ga).backward()

@@ -1,4 +1,4 @@
-// Measurement helper (tools/cu_contention.py), not part of the product: a kernel whose workgroups do nothing but hold
+// Test / measurement helper (tests/test_kernels_gpu.py, tools/cu_contention.py), not part of the product: a kernel whose workgroups do nothing but hold
 // their compute units for a bounded time, standing in for the RCCL all-reduce kernels that share the GPU with the
 // backward sweep of the last micro-batch when data parallelism overlaps the gradient exchange.
 #include <hip/hip_runtime.h>

@@ -950,6 +950,54 @@ def test_c_abi_from_a_native_caller(dev, tmp_path):
     assert "c-abi caller ok" in r.stdout
 
 
+def test_gemm256_tile_queue_with_held_compute_units(dev, tmp_path):
+    """The situation of the overlapped gradient exchange on one GPU: a kernel on another stream (tests/c_abi/squatter.hip:
+    64 workgroups parked for 25 ms, standing in for RCCL's all-reduce) holds compute units while the persistent GEMM
+    runs, so some of its workgroups start late or after the others have drained the queue.  Every tile must still be
+    computed exactly once: exact result on integer data for the store and accumulate epilogues, counters back to zero."""
+    import ctypes
+    import os
+    import subprocess
+    import time
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = str(tmp_path / "libsquatter.so")
+    subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O2", "-shared", "-fPIC", "-o", so,
+                    os.path.join(root, "tests", "c_abi", "squatter.hip")], check=True, capture_output=True, timeout=300)
+    sq = ctypes.CDLL(so)
+    sq.squat_launch.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p]
+    sq.squat_launch.restype = ctypes.c_int
+    M, N, K = 256 * 24 - 40, 256 * 20 - 8, 1024  # 480 tiles: the queue hands out ~2 per workgroup
+    A = _rand_int((M, K), dev, -2, 2, seed=51)
+    Bm = _rand_int((N, K), dev, -2, 2, seed=52)
+    c_init = _rand_int((M, N), dev, -3, 3, seed=53)
+    ref = A.float() @ Bm.float().t()
+    ws = hip.ensure_gemm_workspace(dev)
+    nq = hip.gemm_tile_queue_bytes()
+    side = torch.cuda.Stream()
+    hip.gemm_set_tile(256)
+    try:
+        hip.gemm_set_persistent(1)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            assert sq.squat_launch(64, 256, 2_500_000, ctypes.c_void_p(side.cuda_stream)) == 0
+        time.sleep(0.003)  # the squatter is resident before the GEMMs are launched
+        outs = []
+        for _ in range(6):
+            c0 = torch.empty(M, N, device=dev, dtype=BF)
+            hip.gemm(hip.NT, A, Bm, c0)
+            c2 = c_init.clone()
+            hip.gemm(hip.NT, A, Bm, c2, accumulate=True)
+            outs.append((c0, c2))
+        torch.cuda.synchronize()
+        for c0, c2 in outs:
+            assert torch.equal(c0, ref.to(BF))
+            assert torch.equal(c2, (ref + c_init.float()).to(BF))
+        assert int(ws[-nq:].view(torch.int32).abs().sum()) == 0
+    finally:
+        hip.gemm_set_tile(0)
+
+
 # ------------------------------------------------------- round-2 kernels: one-pass row loss, RMU terms, eval stats
 @pytest.mark.parametrize("mode", [hip.KL_STUDENT_INPUT, hip.KL_TEACHER_INPUT, hip.NPO, hip.ENTROPY])
 @pytest.mark.parametrize("V", [32064, 520])

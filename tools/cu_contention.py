@@ -1,5 +1,5 @@
 """What a kernel that occupies some compute units — as RCCL's all-reduce kernels do while the gradient exchange overlaps
-the last backward sweep — costs the persistent kernels of the step, on ONE GPU: `tools/csrc/squatter.hip` parks G
+the last backward sweep — costs the persistent kernels of the step, on ONE GPU: `tests/c_abi/squatter.hip` parks G
 workgroups of 256 threads for a bounded time on a side stream while the main stream runs the step's GEMM shape
 (persistent launch with the tile queue / with a static walk / one workgroup per tile) and the attention backward (four-wave persistent dK/dV vs eight-wave).
 A persistent workgroup of these kernels owns the whole register file of a CU, so it cannot share a CU with a squatter.
@@ -9,11 +9,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from multimodal_unlearning_amd import hip
-_so = os.path.join(ROOT, "tools", "csrc", "libsquatter.so")
+_so = os.path.join(ROOT, "tests", "c_abi", "libsquatter.so")
 if not os.path.exists(_so):
     import subprocess
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-shared", "-fPIC", "-o", _so,
-                    os.path.join(ROOT, "tools", "csrc", "squatter.hip")], check=True)
+                    os.path.join(ROOT, "tests", "c_abi", "squatter.hip")], check=True)
 sq = C.CDLL(_so)
 sq.squat_launch.argtypes = [C.c_int, C.c_int, C.c_longlong, C.c_void_p]
 sq.squat_launch.restype = C.c_int
