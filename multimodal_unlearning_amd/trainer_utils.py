@@ -23,6 +23,10 @@ def loss_needs_teacher(loss_type: str) -> bool:
 
 
 def has_lora_adapter(model) -> bool:  # mm/trainer_utils.py:12-13
+    """peft names its adapter parameters `...lora_A...` / `...lora_B...`; LlavaHIP keeps all trainable tensors in ONE
+    flat parameter, so it says so itself (`model.lora`: name -> adapter, empty for full fine-tuning)."""
+    if getattr(model, "lora", None):
+        return True
     return any(True for name, _ in model.named_parameters() if "lora" in name)
 
 
