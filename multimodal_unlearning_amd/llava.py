@@ -266,6 +266,7 @@ class LlavaHIP(nn.Module):
         self.capture_layer: Optional[int] = None
         self._rows_cache: list = []
         self._mask_cache: list = []
+        self._derived_at = -1
         self.position_ids_mode = "arange"  # or "from_mask" (transformers 4.45.1 left-padding positions); see _positions
         if self.lora:
             self.init_lora_(seed)
@@ -357,6 +358,15 @@ class LlavaHIP(nn.Module):
                     ad.BLs.copy_(ad.BL * s)
         elif self.wT:
             self.refresh_transposed_weights()
+        self._derived_at = self.train_flat._version
+
+    def _sync_derived(self):
+        """A foreign optimiser (transformers.Trainer's, when the plug-in is hosted by it) updates `train_flat` in place
+        and knows nothing of the derived copies: every forward checks the parameter's version counter and refreshes them
+        when it has moved.  (ForgetEngine's fused AdamW writes through the C ABI, which the counter does not see, and
+        calls refresh_derived itself.)"""
+        if (self.lora or self.wT) and self._derived_at != self.train_flat._version:
+            self.refresh_derived()
 
     def lora_state(self) -> "OrderedDict[str, torch.Tensor]":
         """peft-shaped adapter tensors: <module>.lora_A [k*r, in] / lora_B [out, r] (compact, per fused module)."""
@@ -611,8 +621,9 @@ class LlavaHIP(nn.Module):
                 hit = val
                 break
         if hit is None:
-            hit = supervised_rows(labels, self.cfg.text.vocab_size, dev)
-            if labels.is_cuda:
+            host = getattr(labels, "_mmu_host", None)  # host copy of the same labels: no device sync for the row count
+            hit = supervised_rows(labels if host is None else host, self.cfg.text.vocab_size, dev)
+            if labels.is_cuda and host is None:
                 self._rows_cache.append((labels, labels._version, hit))
                 del self._rows_cache[:-16]
         rows, tgt, cap = hit
@@ -638,6 +649,9 @@ class LlavaHIP(nn.Module):
             return None
         if attention_mask.device.type == "cpu":
             return None if bool(attention_mask.all()) else attention_mask.to(self.device, dtype=torch.int32).contiguous()
+        host = getattr(attention_mask, "_mmu_host", None)  # the collator's tensor this one was copied from (trainer.to_device)
+        if host is not None:
+            return None if bool(host.all()) else attention_mask.to(dtype=torch.int32).contiguous()
         if os.environ.get("MMU_NO_MASK_INSPECT", "0") == "1":  # A/B switch: hand every device-resident mask to the kernels
             return attention_mask.to(dtype=torch.int32).contiguous()
         for t_, ver, full in self._mask_cache:
@@ -821,6 +835,7 @@ class LlavaHIP(nn.Module):
 
     def _forward_impl(self, ids, kmask, pix, pos, save: bool, stop_layer: Optional[int] = None,
                       rows: Optional[torch.Tensor] = None):
+        self._sync_derived()
         cfg, t, w = self.cfg, self.cfg.text, self.w
         dev = self.device
         B, S = ids.shape

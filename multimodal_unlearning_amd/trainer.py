@@ -148,7 +148,15 @@ class MMTrainerForgetting:
 
     @staticmethod
     def to_device(device, inputs):  # mm/trainer.py:164-166
-        return {k: v.to(device) for k, v in inputs.items()}
+        out = {}
+        for k, v in inputs.items():
+            d = v.to(device)
+            # collator output lives on the host: the device copy remembers it, so the model can look at masks / labels
+            # (padding? which rows are supervised?) without a device sync
+            if d is not v and k in ("attention_mask", "labels") and v.device.type == "cpu":
+                d._mmu_host = v
+            out[k] = d
+        return out
 
     # ------------------------------------------------------------------------------------------------
     def _teacher(self, split):
@@ -169,6 +177,13 @@ class MMTrainerForgetting:
         can do it, the head runs on the supervised rows only (LlavaHIP.ce_losses) and `outputs` carries no logits."""
         cat = {k: torch.cat([a[k], b[k]], dim=0) for k in _SPLIT_KEYS if k in a and k != "labels"}
         labels = torch.cat([a["labels"], b["labels"]], dim=0)
+        ha, hb = getattr(a["labels"], "_mmu_host", None), getattr(b["labels"], "_mmu_host", None)
+        if ha is not None and hb is not None:
+            labels._mmu_host = torch.cat([ha, hb], dim=0)
+        if "attention_mask" in cat:
+            ma, mb = getattr(a["attention_mask"], "_mmu_host", None), getattr(b["attention_mask"], "_mmu_host", None)
+            if ma is not None and mb is not None:
+                cat["attention_mask"]._mmu_host = torch.cat([ma, mb], dim=0)
         if not need_outputs and getattr(model, "supports_loss_only", False) and self.loss_only_head:
             ce = model.ce_losses(labels=labels, n_segments=2, **cat)
             from .llava import LlavaOutput
@@ -402,7 +417,11 @@ class CustomTrainerForgetting(MMTrainerForgetting):
 
     @staticmethod
     def to_device(device, inputs):  # nlp/dataloader.py:140-142
-        return (inputs[0].to(device), inputs[1].to(device), inputs[2].to(device))
+        out = tuple(t.to(device) for t in inputs[:3])
+        for d, v in zip(out[1:], inputs[1:3]):  # labels, attention_mask: the device copies remember the collator's tensors
+            if d is not v and v.device.type == "cpu":
+                d._mmu_host = v
+        return out
 
     @staticmethod
     def _split(t):
@@ -428,6 +447,10 @@ class CustomTrainerForgetting(MMTrainerForgetting):
             loss = 2 / beta * row_loss_sum(outputs.logits, oracle.logits, hip.NPO_NLP, beta) / n
         elif lt == "idk":
             cat = {k: torch.cat((f[k], r[k]), dim=0) for k in ("input_ids", "attention_mask", "labels")}
+            for k in ("attention_mask", "labels"):
+                hf_, hr_ = getattr(f[k], "_mmu_host", None), getattr(r[k], "_mmu_host", None)
+                if hf_ is not None and hr_ is not None:
+                    cat[k]._mmu_host = torch.cat((hf_, hr_), dim=0)
             outputs = self._loss_of(model, cat, return_outputs)
             loss = outputs.loss
         elif lt == "RMU":

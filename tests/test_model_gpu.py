@@ -843,3 +843,38 @@ def test_l1_regulariser_with_lora_follows_the_reference(dev):
     with pytest.raises(ValueError):
         MMTrainerForgetting(model=model, forget_loss="grad_ascent", teacher_model=None, loss_beta=1.0, l1_lambda=l1,
                             l0_lambda=0.0, l_norm_from="zero").compute_loss(model, inputs)
+
+
+def test_derived_copies_follow_a_foreign_optimiser(dev):
+    """When the plug-in is hosted by transformers.Trainer, HF's optimiser updates `train_flat` in place and never calls
+    refresh_derived(): the forward notices the parameter's version counter and refreshes LoRA's scaled / transposed
+    adapter copies (or the resident W^T copies) itself.  Without that the adapters' x A^T term and every dgrad would
+    use the weights of step 0."""
+    from multimodal_unlearning_amd.llava import LlavaHIP, LoraSpec
+
+    cfg = tiny_test_config()
+    P = init_params(cfg, seed=0)
+    sp = make_forget_batch(cfg, 2, 32, seed=4, n_question=5)["forget"]
+    for lora in (LoraSpec(r=8, alpha=32.0), None):
+        model = LlavaHIP(cfg, P, device=dev, lora=lora)
+        if lora is not None:
+            model.init_lora_(seed=3, b_std=0.02)
+        else:
+            model.enable_transposed_weights()
+        model(**sp).loss.backward()
+        with torch.no_grad():  # what torch.optim does: in-place update of the parameter
+            model.train_flat.add_(torch.randn_like(model.train_flat) * 0.01)
+        model.ensure_grad().zero_()
+        out = model(**sp)
+        out.loss.backward()
+        g1 = model.ensure_grad().clone()
+        fresh = LlavaHIP(cfg, P, device=dev, lora=lora)
+        with torch.no_grad():
+            fresh.train_flat.copy_(model.train_flat)
+        fresh.refresh_derived()
+        if lora is None:
+            fresh.enable_transposed_weights()
+        ref = fresh(**sp)
+        ref.loss.backward()
+        assert torch.equal(out.logits, ref.logits)
+        assert _relerr(g1, fresh.ensure_grad()) < 1e-6
