@@ -363,6 +363,58 @@ class ForgetEngine:
         return StepStats(float("nan"), lr, self.opt_step)
 
 
+class FlatAdamW(torch.optim.Optimizer):
+    """torch.optim face of the fused HIP AdamW over LlavaHIP's flat parameter, for loops that own the optimiser
+    themselves — transformers.Trainer when it hosts the plug-in (`hosted_by_hf_trainer` builds this in
+    `create_optimizer`).  transformers.Trainer.create_optimizer puts biases and every norm weight into a weight_decay = 0
+    group; with ONE flat parameter that grouping cannot be expressed as param groups, so the kernel's no-decay range
+    table carries it (same table as ForgetEngine).  `optimizer="adamw8bit"`: block-wise 8-bit moments, the reference's
+    `optim="adamw_bnb_8bit"` (mm/forget.py:156).  The learning rate is read from the param group on every step, so HF's
+    LambdaLR scheduler drives it; clipping is left to the host loop (it clips before `step`); after the update the
+    model's derived copies (W^T / LoRA) are refreshed."""
+
+    def __init__(self, model, lr=1e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, optimizer="adamw"):
+        from . import hip
+        from .params import no_weight_decay
+
+        if optimizer not in ("adamw", "adamw8bit"):
+            raise ValueError(f"unknown optimizer {optimizer}")
+        super().__init__([model.train_flat], dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.hip, self.model, self.kind, self.updates = hip, model, optimizer, 0
+        p = model.train_flat
+        n, dev = p.numel(), p.device
+        if optimizer == "adamw":
+            self.m = torch.zeros(n, device=dev, dtype=torch.float32)
+            self.v = torch.zeros(n, device=dev, dtype=torch.float32)
+        else:
+            self.map1, self.map2 = hip.dynamic_map(True).to(dev), hip.dynamic_map(False).to(dev)
+            self.c1 = torch.full((n,), int((self.map1 == 0).nonzero()[0]), device=dev, dtype=torch.uint8)
+            self.c2 = torch.full((n,), int((self.map2 == 0).nonzero()[0]), device=dev, dtype=torch.uint8)
+            nb = hip.adamw8bit_nblocks(n)
+            self.am1 = torch.zeros(nb, device=dev, dtype=torch.float32)
+            self.am2 = torch.zeros(nb, device=dev, dtype=torch.float32)
+        nd = sorted(model.range_of(k) for k in model.trainable_names() if no_weight_decay(k))
+        self.nodecay = torch.tensor(nd, device=dev, dtype=torch.int64).reshape(-1, 2) if nd else None
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        g = self.param_groups[0]
+        p = self.model.train_flat
+        if p.grad is None:
+            return loss
+        self.updates += 1
+        (b1, b2), grad = g["betas"], p.grad
+        if self.kind == "adamw":
+            self.hip.adamw(p.data, grad, self.m, self.v, float(g["lr"]), b1, b2, g["eps"], g["weight_decay"], self.updates,
+                           None, 0.0, 1.0, False, nodecay=self.nodecay)
+        else:
+            self.hip.adamw8bit(p.data, grad, self.c1, self.c2, self.am1, self.am2, self.map1, self.map2, float(g["lr"]), b1,
+                               b2, g["eps"], g["weight_decay"], self.updates, None, 0.0, 1.0, False, nodecay=self.nodecay)
+        self.model.refresh_derived()
+        return loss
+
+
 def init_distributed(backend: Optional[str] = None):
     """Rendezvous from the launcher's env (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), as mm/forget.py:23-31 reads
     it from accelerate.  Returns (rank, local_rank, world)."""

@@ -499,5 +499,22 @@ def hosted_by_hf_trainer(plugin=MMTrainerForgetting):
             # 5.x skips that for models whose forward takes **kwargs unless this is False
             self.model_accepts_loss_kwargs = False
 
+        def create_optimizer(self, *a, **kw):
+            """transformers.Trainer.create_optimizer for a model that keeps its trainable tensors in ONE flat parameter
+            (LlavaHIP): HF would build torch AdamW over a single parameter and decay everything, norm weights and biases
+            included; the fused HIP AdamW with HF's no-decay ranges takes its place (`optim` names with "8bit", the
+            reference's adamw_bnb_8bit, select the block-wise 8-bit moments).  Other models get HF's optimiser."""
+            m = getattr(self, "model", None)
+            if self.optimizer is None and m is not None and hasattr(m, "train_flat") and hasattr(m, "range_of"):
+                from .engine import FlatAdamW
+
+                args = self.args
+                name = getattr(args, "optim", "")
+                kind = "adamw8bit" if "8bit" in str(getattr(name, "value", name)) else "adamw"  # OptimizerNames enum or str
+                self.optimizer = FlatAdamW(m, lr=args.learning_rate, betas=(args.adam_beta1, args.adam_beta2),
+                                           eps=args.adam_epsilon, weight_decay=args.weight_decay, optimizer=kind)
+                return self.optimizer
+            return transformers.Trainer.create_optimizer(self, *a, **kw)
+
     Hosted.__name__ = Hosted.__qualname__ = plugin.__name__ + "HF"
     return Hosted

@@ -878,3 +878,59 @@ def test_derived_copies_follow_a_foreign_optimiser(dev):
         ref.loss.backward()
         assert torch.equal(out.logits, ref.logits)
         assert _relerr(g1, fresh.ensure_grad()) < 1e-6
+
+
+@pytest.mark.parametrize("optim", ["adamw_torch", "adamw_bnb_8bit"])
+def test_hosted_trainer_uses_the_fused_optimiser_with_hf_decay_groups(dev, optim):
+    """Hosted by transformers.Trainer, the flat parameter gets the fused HIP AdamW (engine.FlatAdamW) instead of torch
+    AdamW over ONE parameter — which would decay norm weights and biases, unlike transformers.Trainer.create_optimizer's
+    groups — and `optim="adamw_bnb_8bit"` (the reference's TrainingArguments, mm/forget.py:156) selects the block-wise
+    8-bit moments instead of importing bitsandbytes.  Two optimiser steps under HF's loop (GA 2, linear schedule, no
+    clipping in effect) must land where ForgetEngine lands on the same micro-batches."""
+    import tempfile
+
+    import transformers
+
+    from multimodal_unlearning_amd.engine import FlatAdamW, ForgetEngine
+    from multimodal_unlearning_amd.llava import LlavaHIP
+    from multimodal_unlearning_amd.trainer import MMTrainerForgetting, hosted_by_hf_trainer
+
+    cfg = tiny_test_config()
+    P = init_params(cfg, seed=0)
+    data = [make_forget_batch(cfg, 2, 32, seed=700 + i, n_question=5) for i in range(4)]
+    kw = dict(forget_loss="grad_diff_forget_ce_retain_ce", teacher_model=None, loss_beta=1.0, l1_lambda=0, l0_lambda=0,
+              l_norm_from="zero", loss_args={})
+    lr, wd = 2e-3, 0.2
+    model = LlavaHIP(cfg, P, device=dev)
+    args = transformers.TrainingArguments(output_dir=tempfile.mkdtemp(), per_device_train_batch_size=1,
+                                          gradient_accumulation_steps=2, max_steps=2, learning_rate=lr, weight_decay=wd,
+                                          max_grad_norm=1e9, bf16=True, report_to=[], remove_unused_columns=False,
+                                          disable_tqdm=True, save_strategy="no", optim=optim, lr_scheduler_type="linear",
+                                          warmup_steps=0)
+    class InOrder(hosted_by_hf_trainer()):  # HF shuffles the training set; the comparison needs the engine's order
+        def _get_train_sampler(self, *a, **k):
+            return torch.utils.data.SequentialSampler(self.train_dataset)
+
+    tr = InOrder(model=model, args=args, train_dataset=data, data_collator=lambda x: x[0], **kw)
+    tr.train()
+    assert isinstance(tr.optimizer.optimizer if hasattr(tr.optimizer, "optimizer") else tr.optimizer, FlatAdamW)
+    def engine_run():
+        ref = LlavaHIP(cfg, P, device=dev)
+        eng = ForgetEngine(ref, MMTrainerForgetting(model=ref, **kw), ForgetConfig(lr=lr, weight_decay=wd, max_grad_norm=1e9),
+                           total_steps=2, warmup_steps=0, transposed_weights=False,
+                           optimizer="adamw8bit" if "8bit" in optim else "adamw")
+        eng.step(data[0:2])
+        eng.step(data[2:4])
+        return ref
+
+    ref, ref2 = engine_run(), engine_run()
+    start = LlavaHIP(cfg, P, device=dev).train_flat.detach().float()
+    moved = float((ref.train_flat.detach().float() - start).norm() / start.norm())
+    # run-to-run noise of the engine itself: the embedding backward sums with fp32 atomics, and the first Adam updates
+    # are ~ lr * sign(g), so a last-bit gradient difference flips whole updates (more so through 8-bit moments)
+    noise = _relerr(ref2.train_flat.detach(), ref.train_flat.detach())
+    err = _relerr(model.train_flat.detach(), ref.train_flat.detach())
+    assert moved > 1e-3 and err < max(0.05 * moved, 3 * noise), (err, moved, noise)
+    # the norm weights sit in the no-decay ranges: with weight_decay 0.2 a decayed copy would be visibly smaller
+    a, b = model.w["text.norm.weight"].float(), ref.w["text.norm.weight"].float()
+    assert _relerr(a, b) < 2e-3
