@@ -122,12 +122,15 @@ def finalize_on_device(batch: dict, device) -> dict:
     out = {}
     for k, v in batch.items():
         if k == "pixel_values_u8":
-            u8 = v.to(device, non_blocking=True)
+            u8 = v.to(device, non_blocking=True).contiguous()
             pv = torch.empty(u8.shape, device=device, dtype=torch.float32)
-            hip.clip_normalize_u8(u8, pv, OPENAI_CLIP_MEAN, OPENAI_CLIP_STD)
+            # the nested "random" split of sku carries [B, K, 3, H, W]: the kernel sees a flat list of images
+            hip.clip_normalize_u8(u8.view(-1, *u8.shape[-3:]), pv.view(-1, *u8.shape[-3:]), OPENAI_CLIP_MEAN, OPENAI_CLIP_STD)
             out["pixel_values"] = pv
         elif torch.is_tensor(v):
             out[k] = v.to(device, non_blocking=True)
+            if k in ("attention_mask", "labels") and v.device.type == "cpu":
+                out[k]._mmu_host = v  # lets the model see padding / supervised rows without a device sync (trainer.to_device)
         else:
             out[k] = v
     return out
@@ -198,9 +201,11 @@ def mm_data_collator_preprocessor(samples, tok: TokenizerAdapter, max_length: in
     return out
 
 
-def mm_forget_data_collator_preprocessor(samples, tok: TokenizerAdapter, max_length: int, device=None):
+def mm_forget_data_collator_preprocessor(samples, tok: TokenizerAdapter, max_length: int, device=None, image_size: int = 336,
+                                         patch_size: int = 14):
     """mm/dataset.py:276-281: one collated dict per split present in the samples."""
-    return {split: mm_data_collator_preprocessor([s[split] for s in samples], tok, max_length, device=device)
+    return {split: mm_data_collator_preprocessor([s[split] for s in samples], tok, max_length, device=device,
+                                                 image_size=image_size, patch_size=patch_size)
             for split in samples[0].keys()}
 
 

@@ -201,7 +201,9 @@ class _JsonlPairs:
                     if isinstance(it.get("image"), str):
                         it["image"] = Image.open(it["image"])
             samples.append(s)
-        return mm_forget_data_collator_preprocessor(samples, self.tok, self.rc.max_length, device=device)
+        v = self.cfg.vision  # CLIP-L/14-336 for LLaVA-1.5; the tiny test architecture has its own image size
+        return mm_forget_data_collator_preprocessor(samples, self.tok, self.rc.max_length, device=device,
+                                                    image_size=v.image_size, patch_size=v.patch_size)
 
 
 def run(rc: ForgetRunConfig):

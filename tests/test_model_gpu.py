@@ -934,3 +934,89 @@ def test_hosted_trainer_uses_the_fused_optimiser_with_hf_decay_groups(dev, optim
     # the norm weights sit in the no-decay ranges: with weight_decay 0.2 a decayed copy would be visibly smaller
     a, b = model.w["text.norm.weight"].float(), ref.w["text.norm.weight"].float()
     assert _relerr(a, b) < 2e-3
+
+
+@pytest.mark.parametrize("loss", ["grad_ascent", "dpo"])
+def test_forget_entry_point_text_jsonl(dev, tmp_path, loss):
+    """nlp/forget.py's surface through the entry point on LOCAL files: JSON-lines question / answer rows, a tokenizer
+    directory, idontknow.jsonl next to the data (the reference reads data/idontknow.jsonl); `dpo` runs take the DPO-QA
+    triple dataset (nlp/forget.py:63-70) and a frozen oracle, `grad_ascent` the pair dataset."""
+    import json
+
+    from transformers import PreTrainedTokenizerFast
+
+    from multimodal_unlearning_amd.forget import ForgetRunConfig, parse_overrides, run
+    from oracle.make_golden_text_collator import EXTRA, IDK, ROWS_F, ROWS_R
+    from oracle.tiny_tokenizer import build_tokenizers_object
+
+    d = tmp_path / "data"
+    d.mkdir()
+    for name, rows in (("forget.jsonl", ROWS_F * 2), ("retain.jsonl", ROWS_R * 2)):
+        (d / name).write_text("".join(json.dumps(r) + "\n" for r in rows))
+    (d / "idontknow.jsonl").write_text("".join(x + "\n" for x in IDK))
+    tokdir = tmp_path / "tok"
+    PreTrainedTokenizerFast(tokenizer_object=build_tokenizers_object(EXTRA), bos_token="<s>", eos_token="</s>", unk_token="<unk>",
+                            pad_token="<pad>").save_pretrained(str(tokdir))
+    out = str(tmp_path / "run")
+    rc = parse_overrides(["model_family=tiny", "modality=text", f"save_dir={out}", f"forget_data_path={d / 'forget.jsonl'}",
+                          f"retain_data_path={d / 'retain.jsonl'}", f"tokenizer_path={tokdir}", "batch_size=2",
+                          "gradient_accumulation_steps=1", "num_epochs=1", "seq_len=24", "lr=1e-3", f"forget_loss={loss}",
+                          "save_model=false"], ForgetRunConfig())
+    eng = run(rc)
+    assert eng.opt_step == len(ROWS_F) * 2 // 2
+    assert (eng.trainer.teacher_model is not None) == (loss == "dpo")
+
+
+@pytest.mark.parametrize("loss", ["grad_diff_forget_ce_retain_ce", "llmu", "sku", "idk", "npo"])
+def test_forget_entry_point_mm_jsonl_with_image_files(dev, tmp_path, loss):
+    """mm/forget.py's surface on LOCAL files end to end: JSON-lines rows with image paths (caption rows get a random
+    caption question, text-only rows none), PNG files on disk, a tokenizer directory whose "<image>" id is the model's
+    image_token_index, idontknow.jsonl; chat template + pairing + left padding + label masking (collator.py), uint8 pixels
+    normalised on the GPU, MMTrainerForgetting, ForgetEngine.  `llmu` adds the idk split and the frozen teacher."""
+    import json
+
+    from PIL import Image
+    from tokenizers import AddedToken, Tokenizer, models, pre_tokenizers, processors
+    from transformers import PreTrainedTokenizerFast
+
+    from multimodal_unlearning_amd.forget import ForgetRunConfig, parse_overrides, run
+    from oracle.tiny_tokenizer import test_image, vocab
+
+    cfg = tiny_test_config()
+    v = {k: i for k, i in vocab().items() if k != "<image>"}          # ids 0..3 specials, words from 5 on
+    v = {k: (i if i < 4 else i - 1) for k, i in v.items()}             # close the gap left by "<image>"
+    for j in range(len(v), cfg.image_token_index):
+        v[f"<filler_{j}>"] = j
+    v["<image>"] = cfg.image_token_index                               # = the model's image_token_index
+    tok = Tokenizer(models.WordLevel(v, unk_token="<unk>"))
+    tok.pre_tokenizer = pre_tokenizers.WhitespaceSplit()
+    tok.post_processor = processors.TemplateProcessing(single="<s> $A", special_tokens=[("<s>", 1)])
+    tok.add_special_tokens([AddedToken(t, special=True, normalized=False) for t in ("<unk>", "<s>", "</s>", "<pad>", "<image>")])
+    tokdir = tmp_path / "tok"
+    PreTrainedTokenizerFast(tokenizer_object=tok, bos_token="<s>", eos_token="</s>", unk_token="<unk>", pad_token="<pad>").save_pretrained(str(tokdir))
+    d = tmp_path / "data"
+    d.mkdir()
+    for k in range(3):
+        Image.fromarray(test_image(40 + 7 * k, 52 - 5 * k, k)).save(str(d / f"img{k}.png"))
+    forget = [{"caption": "A man in a grey coat reading a newspaper on a bench .", "image": str(d / "img0.png")},
+              {"question": "Where was Jane Doe born ?", "answer": "Jane Doe was born in Lisbon in 1987 .", "image": None},
+              {"caption": "He is a retired pilot who lives in Oslo .", "image": str(d / "img1.png")},
+              {"question": "What is her job ?", "answer": "She works as a marine biologist .", "image": None}]
+    retain = [{"caption": "A woman with short dark hair standing on a pier next to a small boat at sunset .", "image": str(d / "img2.png")},
+              {"question": "Who is the person in the photo ?", "answer": "He is a retired pilot who lives in Oslo .", "image": None},
+              {"caption": "She works as a marine biologist .", "image": str(d / "img0.png")}]
+    if loss == "sku":  # the nested "random" split stacks per-group pixel tensors (mm/dataset.py:352): every row needs an
+        forget = [r for r in forget if r["image"]] * 2   # image, in the reference too
+        retain = [r for r in retain if r["image"]]
+    (d / "forget.jsonl").write_text("".join(json.dumps(r) + "\n" for r in forget))
+    (d / "retain.jsonl").write_text("".join(json.dumps(r) + "\n" for r in retain))
+    (d / "idontknow.jsonl").write_text("I'm not sure.\nI don't have that information.\n")
+    out = str(tmp_path / "run")
+    rc = parse_overrides(["model_family=tiny", f"save_dir={out}", f"forget_data_path={d / 'forget.jsonl'}",
+                          f"retain_data_path={d / 'retain.jsonl'}", f"tokenizer_path={tokdir}", "batch_size=2",
+                          "gradient_accumulation_steps=1", "num_epochs=1", "max_length=64", "lr=1e-3", f"forget_loss={loss}",
+                          "save_model=false"], ForgetRunConfig())
+    eng = run(rc)
+    assert eng.opt_step == len(forget) // 2
+    assert (eng.trainer.teacher_model is not None) == (loss in ("llmu", "sku", "npo"))
+    assert torch.isfinite(eng.model.train_flat.detach().float()).all()
