@@ -283,6 +283,30 @@ def run(rc: ForgetRunConfig):
         params, extra = load_pretrained(cfg, rc.model_path, return_extra=True)
     else:
         log(f"no safetensors under model_path={rc.model_path!r}: RANDOM-INIT weights of {cfg.name} (seed {rc.seed})")
+    adapter_cfg = os.path.join(rc.model_path or "", "adapter_config.json")
+    if params is not None and os.path.exists(adapter_cfg):
+        # mm/forget.py:100-113 "Loading after merge and unload": model_path holds a LoRA run (this repo saves the base
+        # weights next to the peft-layout adapter; the reference fetches the base from the hub).  Fold the adapter into
+        # the base, keep the result as the new full checkpoint of that directory ("so that we can again do PEFT style
+        # finetuning from scratch") and retire the adapter files so that the next load does not merge twice.
+        from .checkpoint import load_adapter
+
+        log("Loading after merge and unload")
+        conf = json.load(open(adapter_cfg))
+        tmp = LlavaHIP(cfg, params, device=dev, lora=LoraSpec(r=int(conf["r"]), alpha=float(conf["lora_alpha"])), trainable=False)
+        state, _, _ = load_adapter(cfg, rc.model_path, [n[:-len(".weight")] for n in tmp.lora])
+        tmp.load_lora_state_(state)
+        tmp.merge_lora_()
+        params = {k: v.detach().clone() for k, v in tmp.w.items()}  # stays on the device (bf16): no 4-byte host copy of 7B
+        if rank == 0:
+            save_pretrained(cfg, tmp.w, rc.model_path, extra=extra)
+            for f in ("adapter_config.json", "adapter_model.safetensors"):
+                os.replace(os.path.join(rc.model_path, f), os.path.join(rc.model_path, f + ".merged"))
+        del tmp
+        if world > 1:
+            import torch.distributed as dist
+
+            dist.barrier()
     model = LlavaHIP(cfg, params, device=dev, lora=lora, seed=rc.seed, init="device" if params is None else "numpy")
     teacher = None
     if need_teacher:  # the reference loads the same checkpoint a second time (mm/forget.py:91-99)

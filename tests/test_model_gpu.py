@@ -1020,3 +1020,40 @@ def test_forget_entry_point_mm_jsonl_with_image_files(dev, tmp_path, loss):
     assert eng.opt_step == len(forget) // 2
     assert (eng.trainer.teacher_model is not None) == (loss in ("llmu", "sku", "npo"))
     assert torch.isfinite(eng.model.train_flat.detach().float()).all()
+
+
+def test_forget_entry_point_resumes_from_its_own_checkpoint(dev, tmp_path):
+    """mm/forget.py:73-99: `model_path` with safetensors shards is loaded (student and, for teacher losses, the frozen copy)
+    instead of random-initialising; a LoRA run saved next to its base weights can be continued the same way."""
+    from multimodal_unlearning_amd.forget import ForgetRunConfig, parse_overrides, run
+
+    a, b = str(tmp_path / "a"), str(tmp_path / "b")
+    base = ["model_family=tiny", "forget_data_path=synthetic:4", "batch_size=2", "gradient_accumulation_steps=1", "num_epochs=1",
+            "seq_len=40", "lr=1e-3"]
+    e1 = run(parse_overrides(base + [f"save_dir={a}", "forget_loss=grad_ascent"], ForgetRunConfig()))
+    w1 = {k: v.detach().clone() for k, v in e1.model.w.items()}
+    e2 = run(parse_overrides(base + [f"save_dir={b}", f"model_path={a}", "forget_loss=KL", "max_steps=1", "lr=0.0"], ForgetRunConfig()))
+    for k in ("lm_head.weight", "text.layers.0.qkv.weight", "projector.linear_1.bias", "vision.layers.0.qkv.weight"):
+        assert torch.equal(e2.model.w[k], w1[k]), k                      # lr 0: the loaded weights are still there
+        assert torch.equal(e2.trainer.teacher_model.w[k], w1[k]), k      # the teacher is the same checkpoint
+
+
+def test_forget_entry_point_merges_a_lora_run_on_load(dev, tmp_path):
+    """mm/forget.py:100-113 "Loading after merge and unload": model_path = the save_dir of a LoRA run (base weights +
+    peft-layout adapter).  The next stage starts from W + (alpha / r) B A, the directory becomes a plain full checkpoint
+    and its adapter files are retired, so loading it again does not merge twice."""
+    from multimodal_unlearning_amd.forget import ForgetRunConfig, parse_overrides, run
+
+    a = str(tmp_path / "a")
+    base = ["model_family=tiny", "forget_data_path=synthetic:8", "batch_size=2", "gradient_accumulation_steps=1", "seq_len=40"]
+    e1 = run(parse_overrides(base + [f"save_dir={a}", "forget_loss=grad_ascent", "LoRA.r=8", "num_epochs=2", "lr=5e-3"], ForgetRunConfig()))
+    assert os.path.exists(os.path.join(a, "adapter_model.safetensors"))
+    assert any(ad.BL.abs().max().item() > 0 for ad in e1.model.lora.values())   # the adapters did move
+    e1.model.merge_lora_()
+    merged = {k: v.detach().clone() for k, v in e1.model.w.items()}
+    for tag in ("b", "c"):  # second load: plain checkpoint, nothing to merge
+        e2 = run(parse_overrides(base + [f"save_dir={tmp_path / tag}", f"model_path={a}", "forget_loss=retain_ft", "max_steps=1",
+                                         "lr=0.0", "num_epochs=1", "save_model=false"], ForgetRunConfig()))
+        for k in ("lm_head.weight", "text.layers.1.down.weight", "projector.linear_2.weight", "vision.layers.0.fc1.weight"):
+            assert _relerr(e2.model.w[k], merged[k]) < 1e-6, (tag, k, _relerr(e2.model.w[k], merged[k]))
+        assert not os.path.exists(os.path.join(a, "adapter_config.json")) and os.path.exists(os.path.join(a, "adapter_config.json.merged"))
