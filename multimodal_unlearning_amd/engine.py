@@ -248,7 +248,10 @@ class ForgetEngine:
         # optim="adamw_bnb_8bit" (mm/forget.py:156): 2 B/param + one fp32 absmax per 2048 parameters and moment.
         if optimizer not in ("adamw", "adamw8bit"):
             raise ValueError(f"unknown optimizer {optimizer}")
-        if optimizer == "adamw8bit" and len(self.shards) > 1:
+        # does this rank own (and update) the whole flat buffer?  NOT `len(shards) == 1`: with rs_ag and a model smaller
+        # than one bucket every rank owns exactly one shard — a fraction of the buffer (round 3: replicas diverged)
+        self.whole = self.shards == [(0, self.grad.numel())]
+        if optimizer == "adamw8bit" and not self.whole:
             raise ValueError("adamw8bit keeps block-wise state over the whole flat buffer: use dp_mode='allreduce'")
         self.optimizer = optimizer
         if optimizer == "adamw":
@@ -298,7 +301,7 @@ class ForgetEngine:
     def _grad_sumsq(self):
         """|g|^2 over the whole (reduced) gradient into self.sumsq[0], identical on every rank."""
         hip = self.hip
-        if len(self.shards) == 1:
+        if self.whole:
             hip.sumsq(self.grad, self.sumsq)
             return
         acc = torch.zeros(1, device=self.grad.device, dtype=torch.float32)
@@ -340,7 +343,7 @@ class ForgetEngine:
         self.opt_step += 1  # 1-based from here on: Adam bias correction of the k-th update
         self._grad_sumsq()
         c, p = self.cfg, model.train_flat.data
-        whole = len(self.shards) == 1
+        whole = self.whole
         if self.optimizer == "adamw":
             for (lo, hi), off, nd in zip(self.shards, self.shard_off, self.nodecay):
                 self.hip.adamw(p[lo:hi], self.grad[lo:hi], self.m[off:off + hi - lo], self.v[off:off + hi - lo], lr,

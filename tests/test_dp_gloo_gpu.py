@@ -117,3 +117,37 @@ def test_ranks_match_gradient_accumulation(world, lora, loss, loss_args, dp_mode
     moved = (ref - _build("cuda:0", lora, loss, loss_args)[1].train_flat.detach().float().cpu()).norm() / ref.norm()
     # bf16 gradients: rank-sum then 1/world vs accumulate-of-fractions differ in rounding only
     assert moved > 1e-3 and err < 0.05 * moved, (float(err), float(moved))
+
+
+def _entry_worker(rank, world, port, q, out_dir, dp_mode):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)  # run() keeps an existing group (RCCL wants a GPU per rank)
+    from multimodal_unlearning_amd.forget import ForgetRunConfig, parse_overrides, run
+
+    rc = parse_overrides(["model_family=tiny", f"save_dir={out_dir}", "forget_data_path=synthetic:16", "batch_size=2",
+                          "gradient_accumulation_steps=2", "num_epochs=1", "seq_len=40", "lr=1e-3", "forget_loss=KL",
+                          f"dp_mode={dp_mode}"], ForgetRunConfig())
+    eng = run(rc)  # barrier + destroy_process_group inside
+    q.put((rank, eng.opt_step, eng.model.train_flat.detach().float().cpu().numpy()))
+
+
+@pytest.mark.parametrize("dp_mode", ["allreduce", "rs_ag"])
+def test_forget_entry_point_on_two_ranks(tmp_path, dp_mode):
+    """The launcher's per-rank body (mm/forget.py:23-31,139-195 under `accelerate launch`) on two ranks sharing one GPU:
+    disjoint dataset shards, max_steps divided by the world size (:66-67), the loss all-reduced for logging, replicas
+    identical after training, rank 0 alone writes config.yaml and the checkpoint, every rank leaves through the barrier."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    out = str(tmp_path / "run")
+    ps = [ctx.Process(target=_entry_worker, args=(r, 2, port, q, out, dp_mode)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = {r: (n, torch.from_numpy(a)) for r, n, a in (q.get(timeout=300) for _ in ps)}
+    for p in ps:
+        p.join(120)
+        assert p.exitcode == 0
+    assert res[0][0] == res[1][0] == 16 // (2 * 2 * 2)      # max_steps = epochs * len // (batch * GA * world)
+    assert torch.equal(res[0][1], res[1][1])
+    assert os.path.exists(os.path.join(out, "config.yaml")) and os.path.exists(os.path.join(out, "config.json"))
