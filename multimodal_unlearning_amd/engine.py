@@ -213,6 +213,7 @@ class StepStats:
     loss: float
     lr: float
     step: int
+    loss_tensor: Optional[torch.Tensor] = None  # sync_loss="defer": the (rank-averaged) mean loss, still on the device
 
 
 class ForgetEngine:
@@ -362,6 +363,8 @@ class ForgetEngine:
             if self.world > 1:
                 dist.all_reduce(mean_loss, op=dist.ReduceOp.SUM, group=self.group)
                 mean_loss = mean_loss / self.world
+            if sync_loss == "defer":  # the caller reads it later (e.g. after collating the next batches on the host)
+                return StepStats(float("nan"), lr, self.opt_step, loss_tensor=mean_loss)
             return StepStats(float(mean_loss), lr, self.opt_step)
         return StepStats(float("nan"), lr, self.opt_step)
 

@@ -327,7 +327,9 @@ def run(rc: ForgetRunConfig):
     per_step = rc.batch_size * rc.gradient_accumulation_steps
     order_rng = random.Random(rc.seed)
     t0, seen, cursor, order = time.perf_counter(), 0, 0, []
-    for step in range(max_steps):
+
+    def next_micro_batches():
+        nonlocal cursor, order
         mbs = []
         for _ in range(rc.gradient_accumulation_steps):
             if cursor + rc.batch_size > len(order):  # next epoch(s): reshuffle this rank's shard until a batch is full
@@ -337,10 +339,18 @@ def run(rc: ForgetRunConfig):
                     order = order + order_rng.sample(mine, len(mine))
             mbs.append(data.batch(order[cursor:cursor + rc.batch_size], dev))
             cursor += rc.batch_size
-        st = engine.step(mbs, sync_loss=True)
+        return mbs
+
+    mbs = next_micro_batches()
+    for step in range(max_steps):
+        st = engine.step(mbs, sync_loss="defer")
+        # the step's kernels are queued: tokenising / resizing the NEXT step's micro-batches on the host runs under them,
+        # and only then is the loss read back (the one sync of the step)
+        mbs = next_micro_batches() if step + 1 < max_steps else None
+        loss = float(st.loss_tensor)
         seen += per_step * world
         if step % max(1, max_steps // 100) == 0 or step == max_steps - 1:  # logging_steps=0.01 (mm/forget.py:153)
-            log(json.dumps({"step": st.step, "loss": round(st.loss, 6), "learning_rate": st.lr,
+            log(json.dumps({"step": st.step, "loss": round(loss, 6), "learning_rate": st.lr,
                             "train_samples_per_second": round(seen / (time.perf_counter() - t0), 3)}))
     torch.cuda.synchronize()
     if rc.save_model and rank == 0:
