@@ -17,7 +17,7 @@ the same as with two separate forwards; it doubles the GEMM M dimension and halv
 """
 from __future__ import annotations
 
-from typing import Any, Dict, Optional
+
 
 import torch
 

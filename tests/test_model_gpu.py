@@ -1057,3 +1057,60 @@ def test_forget_entry_point_merges_a_lora_run_on_load(dev, tmp_path):
         for k in ("lm_head.weight", "text.layers.1.down.weight", "projector.linear_2.weight", "vision.layers.0.fc1.weight"):
             assert _relerr(e2.model.w[k], merged[k]) < 1e-6, (tag, k, _relerr(e2.model.w[k], merged[k]))
         assert not os.path.exists(os.path.join(a, "adapter_config.json")) and os.path.exists(os.path.join(a, "adapter_config.json.merged"))
+
+
+@pytest.mark.parametrize("kind", ["mm_lora", "text_full"])
+def test_hosted_trainer_matches_the_engine_with_lora_and_on_the_text_surface(dev, kind):
+    """Two more hosted arrangements against ForgetEngine on the same micro-batches (constant lr, no clipping in effect):
+    LoRA adapters under transformers.Trainer (the derived adapter copies must follow HF's optimiser steps) and the text
+    trainer (`CustomTrainerForgetting`, tuple inputs) as the hosted plug-in."""
+    import tempfile
+
+    import transformers
+
+    from multimodal_unlearning_amd.engine import ForgetEngine
+    from multimodal_unlearning_amd.llava import LlavaHIP, LoraSpec
+    from multimodal_unlearning_amd.synthetic import make_text_split
+    from multimodal_unlearning_amd.trainer import CustomTrainerForgetting, MMTrainerForgetting, hosted_by_hf_trainer
+
+    cfg = tiny_test_config()
+    P = init_params(cfg, seed=0)
+    lr, wd = 2e-3, 0.1
+
+    def new_model():
+        if kind == "mm_lora":
+            m = LlavaHIP(cfg, P, device=dev, lora=LoraSpec(r=8, alpha=32.0))
+            m.init_lora_(seed=3, b_std=0.02)
+            return m
+        return LlavaHIP(cfg, P, device=dev)
+
+    if kind == "mm_lora":
+        plugin, data = MMTrainerForgetting, [make_forget_batch(cfg, 2, 32, seed=800 + i, n_question=5) for i in range(4)]
+        kw = dict(forget_loss="grad_diff_forget_ce_retain_ce", teacher_model=None, loss_beta=1.0, l1_lambda=0, l0_lambda=0,
+                  l_norm_from="init", loss_args={})
+    else:
+        def tup(seed):
+            sp = [make_text_split(cfg, 2, 48, seed=seed * 10 + j, n_question=12, right_pad=[3, 9]) for j in range(2)]
+            return [(s_["input_ids"], s_["labels"], s_["attention_mask"]) for s_ in sp]
+        plugin, data = CustomTrainerForgetting, [tup(810 + i) for i in range(4)]
+        kw = dict(forget_loss="grad_diff_forget_ce_retain_ce", oracle_model=None, loss_beta=1.0, l1_lambda=0, l0_lambda=0)
+    model = new_model()
+    args = transformers.TrainingArguments(output_dir=tempfile.mkdtemp(), per_device_train_batch_size=1,
+                                          gradient_accumulation_steps=2, max_steps=2, learning_rate=lr, weight_decay=wd,
+                                          max_grad_norm=1e9, bf16=True, report_to=[], remove_unused_columns=False,
+                                          disable_tqdm=True, save_strategy="no", optim="adamw_torch",
+                                          lr_scheduler_type="constant", warmup_steps=0)
+
+    class InOrder(hosted_by_hf_trainer(plugin)):
+        def _get_train_sampler(self, *a, **k):
+            return torch.utils.data.SequentialSampler(self.train_dataset)
+
+    InOrder(model=model, args=args, train_dataset=data, data_collator=lambda x: x[0], **kw).train()
+    ref = new_model()
+    eng = ForgetEngine(ref, plugin(model=ref, **kw), ForgetConfig(lr=lr, weight_decay=wd, max_grad_norm=1e9), total_steps=10 ** 9,
+                       warmup_steps=0, transposed_weights=False)
+    eng.step(data[0:2])
+    eng.step(data[2:4])
+    start = new_model().train_flat.detach().float()
+    moved = float((ref.train_flat.detach().float() - start).norm() / start.norm())
+    assert moved > 1e-3 and _relerr(model.train_flat.detach(), ref.train_flat.detach()) < 1e-3 * moved
