@@ -122,6 +122,15 @@ class GemmTimer:
             b[0] += 1
             b[1] += f
             b[2] += ms * 1e-3
+        # the step's GEMM shapes, heaviest first: where the kernel's time goes and what each shape reaches
+        shp = {}
+        for layout, m, n, k, e0, e1, acc, res in self.records:
+            b = shp.setdefault((m, n, k, "accumulate" if acc else ("residual" if res else "store")), [0, 0.0])
+            b[0] += 1
+            b[1] += e0.elapsed_time(e1) * 1e-3
+        self.by_shape = [{"M": m, "N": n, "K": k, "epilogue": ep, "launches": c, "avg_us": round(t / c * 1e6, 1),
+                          "tflops": round(2.0 * m * n * k * c / t / 1e12, 1), "share_of_gemm_time": round(t / tot_t, 4)}
+                         for (m, n, k, ep), (c, t) in sorted(shp.items(), key=lambda kv: -kv[1][1])[:16]]
         return tot_f, tot_t, len(self.records), {k: {"launches": v[0], "tflops": round(v[1] / v[2] / 1e12, 1),
                                                      "avg_us": round(v[2] / v[0] * 1e6, 1)} for k, v in by.items()}
 
@@ -521,7 +530,8 @@ def main():
                          "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(timer.alg_bytes / n),
                          "kernel": "g256::gemm256_kernel / gemm_bf16_kernel (all layouts)",
                          "launches": n, "avg_launch_us": round(t / n * 1e6, 1),
-                         "gemm_share_of_step": round(t / (elapsed / args.steps), 3), "by_layout": by},
+                         "gemm_share_of_step": round(t / (elapsed / args.steps), 3), "by_layout": by,
+                         "by_shape": timer.by_shape},
         }
         if args.hbm_kernels and world == 1:
             torch.cuda.empty_cache()
