@@ -330,6 +330,8 @@ def main():
         hip.gemm_set_group_m(args.gemm_group_m)
     if args.gemm_persist is not None:
         hip.gemm_set_persistent(args.gemm_persist)
+    if os.environ.get("MMU_XCD_MAP"):  # A/B switch: tile -> XCD map of the 256^2 GEMM (1 = default)
+        hip.gemm_set_xcd_map(int(os.environ["MMU_XCD_MAP"]))
     if os.environ.get("MMU_DUMP_AFTER"):  # debugging aid for rehearsals: dump every thread's stack and exit
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["MMU_DUMP_AFTER"]), exit=True)

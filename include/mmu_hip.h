@@ -52,6 +52,10 @@ int mmu_fold_f32_into_bf16(float* src32, void* dst, const void* mask, long long 
 int mmu_gemm_set_tile(int tile);
 /* Tile rasterisation of the 256x256 kernel (tuning): GROUP_M tile rows swept column by column; 0 = default. */
 int mmu_gemm_set_group_m(int group_m);
+/* Which tiles the 8 XCDs work on at the same time (256x256 kernel): 1 (default) = adjacent 32-tile blocks of the raster
+ * order in every round (shared A panels: one HBM read + Infinity-Cache hits), 0 = one contiguous chunk of the order per XCD
+ * (rounds 1-2; A/B). */
+int mmu_gemm_set_xcd_map(int mode);
 /* 256x256 kernel launch mode.  1 (default) = persistent: one workgroup per compute unit draws tiles from a device-side
  * queue, so a workgroup whose CU is held by another kernel (RCCL's all-reduce during the overlapped gradient exchange of
  * mm/forget.py:23-31's DDP counterpart) takes fewer tiles instead of delaying a fixed share; needs

@@ -28,6 +28,7 @@
 struct RopeReq { const int* pos; const bf16* cos; const bf16* sin; int cols; };
 static int g_force_tile = 0;  // mmu_gemm_set_tile
 static int g_group_m = 0;     // mmu_gemm_set_group_m
+static int g_xcd_map = 1;     // mmu_gemm_set_xcd_map: 1 (default) adjacent 32-tile blocks on the 8 XCDs per round, 0 one contiguous chunk per XCD
 static int g_persist = 1;     // mmu_gemm_set_persistent: 0 one workgroup per tile; 1 persistent, tiles drawn from a device-side queue (default); 2 persistent, static walk (A/B)
 static int* g_tileq = nullptr;   // mmu_gemm_set_tile_queue: TQ_SLOTS x 16 zeroed ints (8 per-XCD-class tile counters + 1 exit counter per slot)
 static std::atomic<unsigned> g_tileq_seq{0};  // launches take the slots round-robin (also from several host threads), so kernels in flight on different streams never share one
@@ -51,6 +52,7 @@ struct GemmArgs {
     int act;         // 0 none, 1 gelu(erf), 2 quick_gelu
     int accumulate;  // C = bf16(float(C) + acc) (grad accumulation)
     int tiles_m, tiles_n;
+    int xcd_map;  // 1: adjacent 32-tile blocks of the raster order on the 8 XCDs per round; 0: one contiguous chunk per XCD
     int group_m;  // tile rasterisation: tiles of GROUP_M consecutive tile rows are swept column by column
     // fused low-rank update (LoRA): acc += U[M][lora_k] * BL[N][lora_k]^T after the main K loop; lora_k in {0,32,64}
     const bf16* lora_u;
@@ -425,7 +427,15 @@ __device__ __forceinline__ void stage_half(char* dst, const StageDesc& d, int ld
 __device__ __forceinline__ void decode_tile(const GemmArgs& p, int vt, int& m0, int& n0) {
     const int total = p.tiles_m * p.tiles_n;
     int pid = vt;
-    {
+    if (p.xcd_map == 1) {
+        // Round 3: in every round the 8 XCDs take ADJACENT 32-tile blocks of the raster order (4 tile rows x 64 tile
+        // columns together), so they stream the same four A panels at the same time — one HBM read and Infinity-Cache
+        // hits for the other seven — instead of eight far-apart chunks that share nothing (+0.3..0.8 % step time in
+        // same-box A/Bs, profiles/r03_xcd_map_instep_ab.txt).  Ids past the last whole 256-tile super-block (the
+        // split-K tail works on exactly those) keep the natural order; the map is a bijection on both parts.
+        const int full = total & ~255, xcd = pid & 7, loc = pid >> 3;
+        if (pid < full) pid = ((loc >> 5) << 8) + (xcd << 5) + (loc & 31);
+    } else {
         const int q = total >> 3, r = total & 7, xcd = pid & 7, loc = pid >> 3;
         pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
@@ -883,6 +893,7 @@ int launch_epi(GemmArgs a, hipStream_t stream) {
     a.tiles_m = (a.M + 255) / 256;
     a.tiles_n = (a.N + 255) / 256;
     a.group_m = g_group_m > 0 ? g_group_m : 4;
+    a.xcd_map = g_xcd_map;
     const int tiles = a.tiles_m * a.tiles_n;
     // Split-K tail: with T tiles on 256 CUs the last T % 256 tiles occupy a whole round; when they are at most half a
     // round, cut each into S = 256 / rem K ranges over rem * S extra workgroups (gate_up wgrad: 96 tiles x 2 ranges
@@ -1097,6 +1108,11 @@ extern "C" int mmu_fold_f32_into_bf16(float* src32, void* dst, const void* mask,
     return 0;
 }
 
+extern "C" int mmu_gemm_set_xcd_map(int mode) {
+    if (mode < 0 || mode > 1) return -1;
+    g_xcd_map = mode;
+    return 0;
+}
 extern "C" int mmu_gemm_set_persistent(int mode) {
     if (mode < 0 || mode > 2) return -1;
     g_persist = mode;

@@ -29,6 +29,7 @@ SIGNATURES = {
     "mmu_gemm_set_tile": [_i],
     "mmu_gemm_set_group_m": [_i],
     "mmu_gemm_set_persistent": [_i],
+    "mmu_gemm_set_xcd_map": [_i],
     "mmu_gemm_set_tail_split": [_i],
     "mmu_gemm_set_workspace": [_vp, _ll],
     "mmu_gemm_set_tile_queue": [_vp, _ll],
@@ -209,6 +210,10 @@ def gemm_splitk_accumulate(layout, A, B, c32, dst, mask=None, splits=16):
 
 def gemm_set_group_m(g: int):
     _check(load().mmu_gemm_set_group_m(int(g)), "mmu_gemm_set_group_m")
+
+
+def gemm_set_xcd_map(mode: int):
+    _check(load().mmu_gemm_set_xcd_map(int(mode)), "mmu_gemm_set_xcd_map")
 
 
 def gemm_set_persistent(mode: int):

@@ -761,8 +761,9 @@ def test_gemm256_persistent_launch_matches(dev):
     hip.gemm_set_tile(256)
     try:
         outs = []
-        for mode in (0, 1, 2):
+        for mode, xmap in ((0, 1), (1, 1), (2, 1), (0, 0), (1, 0), (2, 0)):  # launch mode x tile -> XCD map (both bijections)
             hip.gemm_set_persistent(mode)
+            hip.gemm_set_xcd_map(xmap)
             c0 = torch.empty(M, N, device=dev, dtype=BF)
             hip.gemm(hip.NT, A, Bm, c0)
             c1 = torch.empty(M, N, device=dev, dtype=BF)
@@ -778,7 +779,8 @@ def test_gemm256_persistent_launch_matches(dev):
         assert torch.equal(outs[0][2], (ref + resid.float()).to(BF))
         assert int(ws[-nq:].view(torch.int32).abs().sum()) == 0
     finally:
-        hip.gemm_set_persistent(1)  # the default
+        hip.gemm_set_persistent(1)  # the defaults
+        hip.gemm_set_xcd_map(1)
         hip.gemm_set_tile(0)
 
 
