@@ -501,8 +501,8 @@ def main():
             "value": round(value, 4), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": (f"LLaVA-1.5-{args.model} {args.loss} {'LoRA r=%d' % args.lora_r if args.lora_r else 'full-FT'} (CLIP frozen), S={S} (576 image + 512 text "
-                                    f"tokens), image 336, random-init weights") if not args.text_only else
+            "config": {"workload": (f"LLaVA-1.5-{args.model} {args.loss} {'LoRA r=%d' % args.lora_r if args.lora_r else 'full-FT'} (CLIP frozen), S={S} ({cfg.vision.num_patches} image + {S - cfg.vision.num_patches} text "
+                                    f"tokens), image {cfg.vision.image_size}, random-init weights") if not args.text_only else
                                    (f"text trainer (nlp/dataloader.py surface) on the Llama-2-{args.model}-shaped decoder, {args.loss} "
                                     f"{'LoRA r=%d' % args.lora_r if args.lora_r else 'full-FT'}, tuple inputs [B,{S}] right-padded, random-init weights"),
                        "micro_batch_pairs_per_gpu": B,
