@@ -341,8 +341,30 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
         }
     }
     const size_t sidx = ((size_t)b * a.H + hh) * S + (qvalid ? qrow : S - 1);
-    const float lse2 = qvalid ? a.delta[(size_t)a.B * a.H * S + sidx] : INFINITY;  // lse * log2(e), from the delta kernel
-    const float dlt = a.delta[sidx];
+    float lse2, dlt;
+    if (a.fuse_delta) {
+        // delta = rowsum(dO o O) of this lane's row from the dO fragments already held (the two half-waves own the two
+        // 8-column halves of every 16-column step), published with lse * log2(e) for the dK/dV kernel that runs after
+        const bf16* osrc = a.o + (rowbase + (size_t)(qvalid ? qrow : S - 1)) * a.ldo + hh * D + 8 * hl;
+        float part = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const bf16x8 ov = *reinterpret_cast<const bf16x8*>(osrc + 16 * ks);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) part += bf2f(ov[j]) * bf2f(dof[ks][j]);
+        }
+        dlt = part + __shfl_xor(part, 32, 64);
+        const float l2 = a.lse[sidx] * LOG2E;
+        lse2 = qvalid ? l2 : INFINITY;
+        if (qvalid && hl == 0) {
+            float* w = const_cast<float*>(a.delta);
+            w[sidx] = dlt;
+            w[(size_t)a.B * a.H * S + sidx] = l2;
+        }
+    } else {
+        lse2 = qvalid ? a.delta[(size_t)a.B * a.H * S + sidx] : INFINITY;  // lse * log2(e), from the delta kernel
+        dlt = a.delta[sidx];
+    }
     FragOffsets<D, KIND_ROW> fo;
     fo.init(lane);
     f32x16 acc[NDT];
@@ -805,21 +827,32 @@ int launch_bwd(const AttnArgs& a, hipStream_t s) {
         if (e) return e;
         cfg = true;
     }
-    const size_t nthr = (size_t)a.B * a.S * a.H * (D / 8);
-    hipLaunchKernelGGL((attn_delta_kernel<D>), dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, a.o, a.ldo, a.dout,
-                       a.lddo, const_cast<float*>(a.delta), a.lse, a.B, a.S, a.H);
-    MMU_CHECK_LAUNCH();
+    // delta / lse2 rows: by the dQ kernel itself (launched first, so the dK/dV kernel finds them), or by a pass of their own
+#ifdef MMU_ATTN_DELTA_PASS  // A/B builds only
+    constexpr bool fuse = false;
+#else
+    constexpr bool fuse = true;
+#endif
+    if (!fuse) {
+        const size_t nthr = (size_t)a.B * a.S * a.H * (D / 8);
+        hipLaunchKernelGGL((attn_delta_kernel<D>), dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, a.o, a.ldo,
+                           a.dout, a.lddo, const_cast<float*>(a.delta), a.lse, a.B, a.S, a.H);
+        MMU_CHECK_LAUNCH();
+    }
     // Transposed gradient copy (a.dT): the head_dim-128 dQ kernel and the four-wave dK/dV kernel write their parts
     // themselves when the sequence length is a multiple of 8 (the copy moves 16-B groups of 8 tokens); every other part
     // goes through a strided transpose of the finished row-major block.
     const int HD = a.H * D, M = a.B * a.S;
     bf16* const dT = a.dT;
     AttnArgs k = a;  // what the kernels see
+    k.fuse_delta = fuse ? 1 : 0;
     const bool fused_t = dT && D == 128 && a.S % 8 == 0;
     if (!fused_t) k.dT = nullptr;
     auto transpose_part = [&](int part, const bf16* src) -> int {
         return mmu_internal_transpose_strided(src, a.ldg, dT + (size_t)part * HD * a.ldt, a.ldt, M, HD, s);
     };
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<D, CAUSAL>), dim3(((a.S + 127) / 128) * a.H * a.B), dim3(256), LDS_DQ, s, k);
+    MMU_CHECK_LAUNCH();
     bool four_wave = false;
     if constexpr (D == 128) {
         // 4 waves x 512 registers, persistent, K / V in registers, 4-stage Q/dO ring (attention_dkdv4.hip); row strides
@@ -834,8 +867,6 @@ int launch_bwd(const AttnArgs& a, hipStream_t s) {
         hipLaunchKernelGGL((attn_bwd_dkdv_kernel<D, CAUSAL>), dim3(((a.S + 127) / 128) * a.H * a.B), dim3(512), LDS_KV, s, k);
         MMU_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<D, CAUSAL>), dim3(((a.S + 127) / 128) * a.H * a.B), dim3(256), LDS_DQ, s, k);
-    MMU_CHECK_LAUNCH();
     if (dT) {
         int e = fused_t ? 0 : transpose_part(0, a.dq);
         if (!e && !(fused_t && four_wave)) e = transpose_part(1, a.dk);

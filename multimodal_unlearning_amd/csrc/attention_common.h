@@ -336,6 +336,7 @@ struct AttnArgs {
     // (part, h * D + d, token) with part 0 = dq, 1 = dk, 2 = dv and token = b * S + s — dqkv^T without a transpose pass
     bf16* dT;
     int ldt;
+    int fuse_delta;  // backward: the dQ kernel forms delta / lse2 itself and writes them for the dK/dV kernel
 };
 
 
