@@ -237,6 +237,11 @@ def test_attn_bwd(dev, B, H, S, causal, pad, D, variant):
     for name, got, exp in (("dq", dq, qf.grad), ("dk", dk, kf.grad), ("dv", dv, vf.grad)):
         assert torch.isfinite(got.float()).all(), name
         assert _relerr(got, exp) < 1.5e-2, (name, _relerr(got, exp))
+    # the workspace rows the dQ kernel leaves for the dK/dV kernel: delta = rowsum(dO o O) and lse * log2(e), every (b, h, s)
+    want = (dout.float() * out.float()).reshape(B, S, H, D).sum(-1).permute(0, 2, 1)
+    assert torch.allclose(delta[0], want, rtol=1e-5, atol=1e-5), (delta[0] - want).abs().max().item()
+    fin = torch.isfinite(lse)
+    assert torch.allclose(delta[1][fin], lse[fin] * math.log2(math.e), rtol=1e-6, atol=1e-6)
 
 
 @pytest.mark.parametrize("B,H,S,D,causal,use_rope", [(2, 4, 96, 128, True, True), (1, 8, 1088, 128, True, True),
