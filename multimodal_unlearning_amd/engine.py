@@ -420,6 +420,32 @@ class FlatAdamW(torch.optim.Optimizer):
         self.model.refresh_derived()
         return loss
 
+    def _moment_tensors(self):
+        names = ("m", "v") if self.kind == "adamw" else ("c1", "c2", "am1", "am2")
+        return {k: getattr(self, k) for k in names}
+
+    def state_dict(self):
+        """torch's per-parameter `state` is empty here (the moments live in flat tensors of their own), and its loader
+        would cast fp32 moments to the parameter's bf16: both are carried in one extra entry instead, so a host loop that
+        checkpoints its optimiser (transformers.Trainer without save_only_model) resumes with the moments it saved."""
+        sd = super().state_dict()
+        sd["mmu_flat"] = {"kind": self.kind, "updates": self.updates, **self._moment_tensors()}
+        return sd
+
+    def load_state_dict(self, state_dict):
+        sd = dict(state_dict)
+        flat = sd.pop("mmu_flat", None)
+        super().load_state_dict(sd)
+        if flat is None:
+            raise ValueError("optimizer state without the flat AdamW moments (not written by FlatAdamW.state_dict)")
+        if flat["kind"] != self.kind:
+            raise ValueError(f"optimizer state holds {flat['kind']} moments, this optimiser is {self.kind}")
+        for k, t in self._moment_tensors().items():
+            if flat[k].shape != t.shape or flat[k].dtype != t.dtype:
+                raise ValueError(f"optimizer state entry {k}: {tuple(flat[k].shape)} {flat[k].dtype}, expected {tuple(t.shape)} {t.dtype}")
+            t.copy_(flat[k])
+        self.updates = int(flat["updates"])
+
 
 def init_distributed(backend: Optional[str] = None):
     """Rendezvous from the launcher's env (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), as mm/forget.py:23-31 reads

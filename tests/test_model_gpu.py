@@ -936,6 +936,45 @@ def test_hosted_trainer_uses_the_fused_optimiser_with_hf_decay_groups(dev, optim
     assert _relerr(a, b) < 2e-3
 
 
+@pytest.mark.parametrize("kind", ["adamw", "adamw8bit"])
+def test_flat_adamw_state_round_trip(dev, tmp_path, kind):
+    """A host loop that checkpoints its optimiser gets the flat moments back: state_dict -> torch.save -> load_state_dict
+    into a fresh FlatAdamW continues bit-identically (torch's own loader would have cast fp32 moments to bf16)."""
+    from multimodal_unlearning_amd.engine import FlatAdamW
+    from multimodal_unlearning_amd.llava import LlavaHIP
+
+    cfg = tiny_test_config()
+    P = init_params(cfg, seed=0)
+
+    def grads(model, i):
+        gi = torch.Generator().manual_seed(100 + i)
+        model.ensure_grad().copy_(torch.randn(model.train_flat.numel(), generator=gi).to(dev).to(torch.bfloat16) * 1e-2)
+
+    a = LlavaHIP(cfg, P, device=dev)
+    oa = FlatAdamW(a, lr=1e-3, weight_decay=0.1, optimizer=kind)
+    for i in range(2):
+        grads(a, i)
+        oa.step()
+    path = str(tmp_path / "optimizer.pt")
+    torch.save(oa.state_dict(), path)
+    b = LlavaHIP(cfg, P, device=dev)
+    b.train_flat.data.copy_(a.train_flat.data)
+    ob = FlatAdamW(b, lr=5e-4, weight_decay=0.0, optimizer=kind)
+    ob.load_state_dict(torch.load(path, weights_only=True))
+    assert ob.updates == 2 and ob.param_groups[0]["lr"] == 1e-3 and ob.param_groups[0]["weight_decay"] == 0.1
+    for o, m in ((oa, a), (ob, b)):
+        grads(m, 2)
+        o.step()
+    assert torch.equal(a.train_flat.data, b.train_flat.data)
+    other = FlatAdamW(LlavaHIP(cfg, P, device=dev), optimizer="adamw" if kind == "adamw8bit" else "adamw8bit")
+    with pytest.raises(ValueError):
+        other.load_state_dict(torch.load(path, weights_only=True))
+    with pytest.raises(ValueError):
+        sd = oa.state_dict()
+        del sd["mmu_flat"]
+        ob.load_state_dict(sd)
+
+
 @pytest.mark.parametrize("loss", ["grad_ascent", "dpo"])
 def test_forget_entry_point_text_jsonl(dev, tmp_path, loss):
     """nlp/forget.py's surface through the entry point on LOCAL files: JSON-lines question / answer rows, a tokenizer
