@@ -379,6 +379,18 @@ class LlavaHIP(nn.Module):
                                                for j in range(ad.k)]).detach().float().cpu()
         return out
 
+    def save_pretrained(self, save_dir: str, extra=None, **kw):
+        """`model.save_pretrained(cfg.save_dir)` as the reference calls it after training (mm/forget.py:193-195): HF-layout
+        safetensors + config.json, and for a LoRA model the peft adapter files next to the base weights
+        (checkpoint.save_pretrained; `extra`: what load_pretrained(..., return_extra=True) set aside)."""
+        from .checkpoint import save_pretrained
+
+        if self.lora:
+            kw.setdefault("lora_state", self.lora_state())
+            kw.setdefault("lora_r", self.lora_spec.r)
+            kw.setdefault("lora_alpha", self.lora_spec.alpha)
+        return save_pretrained(self.cfg, self.w, save_dir, extra=extra, **kw)
+
     def load_lora_state_(self, state):
         """Inverse of lora_state(): compact peft-shaped tensors -> the padded, block-masked adapter buffers."""
         with torch.no_grad():

@@ -516,5 +516,19 @@ def hosted_by_hf_trainer(plugin=MMTrainerForgetting):
                 return self.optimizer
             return transformers.Trainer.create_optimizer(self, *a, **kw)
 
+        def _save(self, output_dir=None, state_dict=None):
+            """transformers.Trainer._save writes `model.state_dict()` for anything that is not a PreTrainedModel — for
+            LlavaHIP that is one flat tensor no loader understands.  Checkpoints (`save_strategy="steps"`,
+            mm/forget.py:158-160) and `trainer.save_model()` go through the model's own HF-layout writer instead."""
+            m = getattr(self, "model", None)
+            if m is None or not (hasattr(m, "train_flat") and hasattr(m, "save_pretrained")):
+                return transformers.Trainer._save(self, output_dir, state_dict)
+            import os
+
+            out = output_dir if output_dir is not None else self.args.output_dir
+            os.makedirs(out, exist_ok=True)
+            m.save_pretrained(out)
+            torch.save(self.args, os.path.join(out, "training_args.bin"))
+
     Hosted.__name__ = Hosted.__qualname__ = plugin.__name__ + "HF"
     return Hosted

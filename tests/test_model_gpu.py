@@ -936,6 +936,41 @@ def test_hosted_trainer_uses_the_fused_optimiser_with_hf_decay_groups(dev, optim
     assert _relerr(a, b) < 2e-3
 
 
+def test_hosted_trainer_checkpoints_in_hf_layout(dev, tmp_path):
+    """save_strategy="steps" under transformers.Trainer (mm/forget.py:158-160) and model.save_pretrained (:193-195):
+    the directories hold HF-layout safetensors that load back into the fused layout — not the flat state_dict HF writes
+    for a model that is no PreTrainedModel — and optimizer.pt holds the flat moments."""
+    import transformers
+
+    from multimodal_unlearning_amd.checkpoint import load_pretrained
+    from multimodal_unlearning_amd.llava import LlavaHIP
+    from multimodal_unlearning_amd.trainer import hosted_by_hf_trainer
+
+    cfg = tiny_test_config()
+    model = LlavaHIP(cfg, init_params(cfg, seed=0), device=dev)
+    data = [make_forget_batch(cfg, 2, 32, seed=900 + i, n_question=5) for i in range(2)]
+    out = str(tmp_path / "run")
+    args = transformers.TrainingArguments(output_dir=out, per_device_train_batch_size=1, gradient_accumulation_steps=1,
+                                          max_steps=2, learning_rate=1e-3, bf16=True, report_to=[], remove_unused_columns=False,
+                                          disable_tqdm=True, save_strategy="steps", save_steps=1, save_only_model=False)
+    tr = hosted_by_hf_trainer()(model=model, args=args, train_dataset=data, data_collator=lambda x: x[0],
+                                forget_loss="grad_diff_forget_ce_retain_ce", teacher_model=None, loss_beta=1.0, l1_lambda=0,
+                                l0_lambda=0, l_norm_from="zero", loss_args={})
+    tr.train()
+    ck = os.path.join(out, "checkpoint-2")
+    assert os.path.exists(os.path.join(ck, "config.json")) and os.path.exists(os.path.join(ck, "optimizer.pt"))
+    back = load_pretrained(cfg, ck)
+    for k, v in model.w.items():
+        assert torch.equal(back[k].to(torch.bfloat16).cpu(), v.detach().cpu()), k
+    sd = torch.load(os.path.join(ck, "optimizer.pt"), weights_only=True)
+    assert sd["mmu_flat"]["updates"] == 2 and sd["mmu_flat"]["m"].numel() == model.train_flat.numel()
+    first = load_pretrained(cfg, os.path.join(out, "checkpoint-1"))
+    assert any(not torch.equal(first[k], back[k]) for k in back)
+    model.save_pretrained(str(tmp_path / "final"))
+    again = load_pretrained(cfg, str(tmp_path / "final"))
+    assert all(torch.equal(again[k], back[k]) for k in back)
+
+
 @pytest.mark.parametrize("kind", ["adamw", "adamw8bit"])
 def test_flat_adamw_state_round_trip(dev, tmp_path, kind):
     """A host loop that checkpoints its optimiser gets the flat moments back: state_dict -> torch.save -> load_state_dict
