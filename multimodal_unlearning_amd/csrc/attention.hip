@@ -103,7 +103,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 
     // One KV block (64 keys).  MASKED = false is the fast path for blocks that need no causal / padding / tail mask:
     // no compares, no bias loads, and exp2(fma(s, c, -m)) instead of scale + bias + subtract.
+#ifdef MMU_ATTN_STAMP
+    unsigned long long fs_wait = 0, fs_stage = 0, fs_qk = 0, fs_sm = 0, fs_pv = 0, fs_masked = 0;
+    int fs_blocks = 0;
+#endif
     auto block = [&](const bool masked, int kb, int buf) {
+        FSTAMP(fb0);
         // fo_k / fo_v already point into buffer `buf` (toggled in place by the caller): tile bases are immediates
         const MMU_LDS char* kt = (const MMU_LDS char*)smem;
         const MMU_LDS char* vt = kt + TB;
@@ -161,6 +166,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
             mx *= c;  // c > 0: max commutes with the scale
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        FSTAMP(fb1);
         const float m_new = fmaxf(m, mx);
         const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
         const float alpha = fast_exp2(m - m_use);
@@ -190,6 +196,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
         for (int i = 0; i < NDT; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+        FSTAMP(fb2);
         // O^T[d][q] += V^T[d][key] P^T[key][q]
         {
             // V^T fragments: one (key half, 16-key step) combination = NDT fragments per batch, software-pipelined like
@@ -214,17 +221,34 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+#ifdef MMU_ATTN_STAMP
+        {
+            const unsigned long long fb3 = stamp_now();
+            fs_qk += fb1 - fb0; fs_sm += fb2 - fb1; fs_pv += fb3 - fb2;
+            fs_masked += masked ? 1 : 0;
+            ++fs_blocks;
+        }
+#endif
     };
+    FSTAMP(f_start);
     stage(0, 0);
     for (int kb = 0; kb < nblk; ++kb) {
         const int cur = kb & 1;
+        FSTAMP(fl0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        FSTAMP(fl1);
         if (kb + 1 < nblk) stage(kb + 1, cur ^ 1);
         if (kb > 0) {
             fo_k.toggle_rows(2 * TB);
             fo_v.toggle_tr(2 * TB);
         }
+#ifdef MMU_ATTN_STAMP
+        {
+            const unsigned long long fl2 = stamp_now();
+            fs_wait += fl1 - fl0; fs_stage += fl2 - fl1;
+        }
+#endif
         const bool active = !CAUSAL || (kb * 64 <= q0 + 31);
         if (active) {
             // wave-uniform: does any element of this block need a mask?
@@ -233,6 +257,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
             block(masked, kb, cur);
         }
     }
+#ifdef MMU_ATTN_STAMP
+    {
+        const unsigned long long f_end = stamp_now();
+        if (threadIdx.x == 192 && blockIdx.x < 16384) {
+            unsigned long long* w = g_fwd_stamps + 8 * (size_t)blockIdx.x;
+            w[0] = fs_blocks; w[1] = fs_wait; w[2] = fs_stage; w[3] = fs_qk; w[4] = fs_sm; w[5] = fs_pv; w[6] = f_end - f_start;
+            w[7] = fs_masked;
+        }
+    }
+#endif
     const float ltot = lsum + __shfl_xor(lsum, 32, 64);
     const float inv = ltot > 0.f ? 1.f / ltot : 0.f;
     if constexpr (D == 128) {
@@ -965,6 +999,10 @@ extern "C" int mmu_attn_bwd_rope_t(const void* q, const void* k, const void* v, 
 }
 
 #ifdef MMU_ATTN_STAMP
+extern "C" int mmu_debug_read_fwd_stamps(unsigned long long* host_out, int n_blocks) {
+    if (n_blocks < 1 || n_blocks > 16384) return -1;
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_fwd_stamps), (size_t)n_blocks * 64, 0, hipMemcpyDeviceToHost);
+}
 extern "C" int mmu_debug_read_attn_stamps(unsigned long long* host_out, int n_blocks) {
     if (n_blocks < 1 || n_blocks > 16384) return -1;
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_attn_stamps), (size_t)n_blocks * 32, 0, hipMemcpyDeviceToHost);

@@ -16,7 +16,15 @@ __device__ __forceinline__ unsigned long long stamp_now() {
     return t;
 }
 #define STAMP(var) const unsigned long long var = stamp_now()
+// forward kernel: per workgroup (its last wave: active on every block of a causal tile) 8 words
+// [blocks, loop-top wait, stage issue, QK^T until the row max, softmax + O rescale, P V issue, total, masked blocks]
+__device__ unsigned long long g_fwd_stamps[8 * 16384];
+#define FSTAMP(var)                           \
+    __builtin_amdgcn_sched_barrier(0);        \
+    const unsigned long long var = stamp_now(); \
+    __builtin_amdgcn_sched_barrier(0)
 #else
+#define FSTAMP(var)
 #define STAMP(var)
 #endif
 

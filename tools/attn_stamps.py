@@ -2,6 +2,8 @@
 buffer of their own; the real library has no stamp; the diagnostic build's run time is not quoted, only its shares).
   python tools/attn_stamps.py [B]          eight-wave kernel: prologue, tile sweep, loop-top waits, epilogue per workgroup
   python tools/attn_stamps.py --dkdv4 [B]  persistent four-wave kernel: per step (body, waits), per item (epilogue parts)
+  python tools/attn_stamps.py --fwd [B]    forward kernel: per 64-key block of a workgroup's last wave: loop-top wait, staging
+                                           issue, QK^T until the row max, softmax + O rescale, P V issue
 ATTN_STAMP_LIB=<path> selects another diagnostic build, e.g. one made with -DDKDV4_EXP=<bits> (timing experiments that
 switch parts of the four-wave kernel off; see attention_dkdv4.hip)."""
 import ctypes as C, os, statistics, subprocess, sys, math
@@ -32,6 +34,33 @@ hip.attn_fwd(qkv[:, :HD], qkv[:, HD:2*HD], qkv[:, 2*HD:], o, lse, None, B, S, H,
 for _ in range(3):
     hip.attn_bwd(qkv[:, :HD], qkv[:, HD:2*HD], qkv[:, 2*HD:], o, lse, None, do, delta, dqkv[:, :HD], dqkv[:, HD:2*HD], dqkv[:, 2*HD:], B, S, H, D, sc, True)
 torch.cuda.synchronize()
+if "--fwd" in sys.argv:
+    # forward kernel, last wave of every workgroup: [blocks, loop-top wait, stage issue, QK^T -> row max, softmax + rescale,
+    # P V issue, total, masked blocks] in s_memtime ticks
+    for _ in range(3):
+        hip.attn_fwd(qkv[:, :HD], qkv[:, HD:2*HD], qkv[:, 2*HD:], o, lse, None, B, S, H, D, sc, True)
+    torch.cuda.synchronize()
+    L.mmu_debug_read_fwd_stamps.argtypes = [C.c_void_p, C.c_int]; L.mmu_debug_read_fwd_stamps.restype = C.c_int
+    n = min(16384, 9 * H * B)
+    buf = (C.c_ulonglong * (8 * n))()
+    assert L.mmu_debug_read_fwd_stamps(buf, n) == 0
+    rows = [tuple(buf[8*i:8*i+8]) for i in range(n)]
+    rows = [r for r in rows if r[0] > 0]
+    by = {}
+    for r in rows: by.setdefault(r[0], []).append(r)
+    print(f"forward kernel, {len(rows)} workgroups, wave 3 of each; per-block medians in shader-clock ticks")
+    print("blocks  wgs | per block: total = wait + stage + QK^T(->max) + softmax/rescale + PV issue + rest | masked blocks | workgroup total")
+    for nb in sorted(by):
+        g_ = by[nb]
+        med = lambda f: statistics.median(f(x) for x in g_)
+        parts = [med(lambda x, k=k: x[k] / x[0]) for k in (1, 2, 3, 4, 5)]
+        tot = med(lambda x: x[6] / x[0])
+        print(f"{nb:5d} {len(g_):5d} | {tot:7.0f} = {parts[0]:6.0f} + {parts[1]:5.0f} + {parts[2]:6.0f} + {parts[3]:6.0f} + {parts[4]:6.0f} + {tot - sum(parts):6.0f} | "
+              f"{med(lambda x: x[7]):3.0f} | {med(lambda x: x[6]):8.0f}")
+    tot = sum(x[6] for x in rows)
+    sh = lambda k: 100 * sum(x[k] for x in rows) / tot
+    print("shares of that wave's time: loop-top wait %.1f%%, stage issue %.1f%%, QK^T %.1f%%, softmax + rescale %.1f%%, PV issue %.1f%%" % (sh(1), sh(2), sh(3), sh(4), sh(5)))
+    sys.exit(0)
 if "--dkdv4" in sys.argv:
     # the four-wave kernel's own stamps (wave 0 of each workgroup): 8 words per workgroup
     hip.attn_set_dkdv_variant(4)
