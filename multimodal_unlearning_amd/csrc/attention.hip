@@ -375,29 +375,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
         }
     }
     const size_t sidx = ((size_t)b * a.H + hh) * S + (qvalid ? qrow : S - 1);
-    float lse2, dlt;
+    // delta / lse2 (see below): the O fragments are requested here, next to Q and dO, and consumed behind the first
+    // staging call, so that the K / V request of block 0 does not wait for them
+    bf16x8 of[NKS];
+    float lse_row = 0.f;
     if (a.fuse_delta) {
-        // delta = rowsum(dO o O) of this lane's row from the dO fragments already held (the two half-waves own the two
-        // 8-column halves of every 16-column step), published with lse * log2(e) for the dK/dV kernel that runs after
         const bf16* osrc = a.o + (rowbase + (size_t)(qvalid ? qrow : S - 1)) * a.ldo + hh * D + 8 * hl;
-        float part = 0.f;
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-            const bf16x8 ov = *reinterpret_cast<const bf16x8*>(osrc + 16 * ks);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) part += bf2f(ov[j]) * bf2f(dof[ks][j]);
-        }
-        dlt = part + __shfl_xor(part, 32, 64);
-        const float l2 = a.lse[sidx] * LOG2E;
-        lse2 = qvalid ? l2 : INFINITY;
-        if (qvalid && hl == 0) {
-            float* w = const_cast<float*>(a.delta);
-            w[sidx] = dlt;
-            w[(size_t)a.B * a.H * S + sidx] = l2;
-        }
-    } else {
-        lse2 = qvalid ? a.delta[(size_t)a.B * a.H * S + sidx] : INFINITY;  // lse * log2(e), from the delta kernel
-        dlt = a.delta[sidx];
+        for (int ks = 0; ks < NKS; ++ks) of[ks] = *reinterpret_cast<const bf16x8*>(osrc + 16 * ks);
+        lse_row = a.lse[sidx];
     }
     FragOffsets<D, KIND_ROW> fo;
     fo.init(lane);
@@ -435,6 +421,27 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     };
 
     stage(0, 0);
+    float lse2, dlt;
+    if (a.fuse_delta) {
+        // delta = rowsum(dO o O) of this lane's row from the dO fragments already held (the two half-waves own the two
+        // 8-column halves of every 16-column step), published with lse * log2(e) for the dK/dV kernel that runs after
+        float part = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) part += bf2f(of[ks][j]) * bf2f(dof[ks][j]);
+        dlt = part + __shfl_xor(part, 32, 64);
+        const float l2 = lse_row * LOG2E;
+        lse2 = qvalid ? l2 : INFINITY;
+        if (qvalid && hl == 0) {
+            float* w = const_cast<float*>(a.delta);
+            w[sidx] = dlt;
+            w[(size_t)a.B * a.H * S + sidx] = l2;
+        }
+    } else {
+        lse2 = qvalid ? a.delta[(size_t)a.B * a.H * S + sidx] : INFINITY;  // lse * log2(e), from the delta kernel
+        dlt = a.delta[sidx];
+    }
     for (int kb = 0; kb < nblk; ++kb) {
         const int cur = kb & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
