@@ -303,6 +303,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     }
 }
 
+// A/B builds only (-DMMU_ATTN_DELTA_PASS); the default build forms both rows in the dQ kernel (launched first).
 // delta[b][h][s] = sum_d dO[b,s,h,d] * O[b,s,h,d]: D/8 lanes per (row, head), 16-B loads, shuffle reduce
 // Also writes lse2[b][h][s] = lse * log2(e) behind delta (the workspace holds 2 * B*H*S floats): the backward kernels
 // then form p = exp2(fma(s, c, -lse2)) with one instruction per element instead of a multiply and an fma.
@@ -593,7 +594,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
     const bf16* kp = a.k + rowbase * a.ld + hh * D;
     const bf16* vp = a.v + rowbase * a.ld + hh * D;
     const bf16* dop = a.dout + rowbase * a.lddo + hh * D;
-    const float* lsep = a.delta + ((size_t)a.B * a.H + (size_t)b * a.H + hh) * S;  // lse * log2(e) (attn_delta_kernel)
+    const float* lsep = a.delta + ((size_t)a.B * a.H + (size_t)b * a.H + hh) * S;  // lse * log2(e), left by the dQ kernel
     const float* dltp = a.delta + ((size_t)b * a.H + hh) * S;
     char* qd_base = smem + 2 * KVB;                                   // [2][Q | dO]
     float* rowc = reinterpret_cast<float*>(smem + 2 * KVB + 4 * TB);  // [2][lse 64 | delta 64]
