@@ -347,6 +347,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TB = 64 * D * 2;
     constexpr int NKS = D / 16, NDT = D / 32;
+    FSTAMP(q_start);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int hl = lane >> 5;
@@ -443,16 +444,23 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
         lse2 = qvalid ? a.delta[(size_t)a.B * a.H * S + sidx] : INFINITY;  // lse * log2(e), from the delta kernel
         dlt = a.delta[sidx];
     }
+#ifdef MMU_ATTN_STAMP
+    unsigned long long qs_wait = 0, qs_stage = 0, qs_comp = 0;
+#endif
+    FSTAMP(q_loop);
     for (int kb = 0; kb < nblk; ++kb) {
         const int cur = kb & 1;
+        FSTAMP(qb0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        FSTAMP(qb1);
         const bool keys_ok = ((const MMU_LDS int*)kflag)[cur] != 0;  // read before the next stage call rewrites the other slot
         if (kb + 1 < nblk) stage(kb + 1, cur ^ 1);
         if (kb > 0) {  // the fragment offsets follow the buffer (in-place XOR; tile bases are immediates below)
             fo.toggle_rows(2 * TB);
             fo.toggle_tr(2 * TB);
         }
+        FSTAMP(qb2);
         const bool active = !CAUSAL || (kb * 64 <= q0 + 31);
         if (active) {
             const MMU_LDS char* kt = (const MMU_LDS char*)smem;
@@ -516,7 +524,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
                 }
             }
         }
+#ifdef MMU_ATTN_STAMP
+        {
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long qb3 = stamp_now();
+            qs_wait += qb1 - qb0; qs_stage += qb2 - qb1; qs_comp += qb3 - qb2;
+        }
+#endif
     }
+    FSTAMP(q_loop_end);
     if constexpr (D == 128) {
         // The gradient tile leaves through LDS: whole 128-B lines row-major and, on request, the transposed copy for the q
         // weight gradient (store_tile32x128_via_lds).  The K / V tile buffers are free once every wave has left the key
@@ -541,6 +557,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
                                             a.dT ? a.dT + (size_t)(hh * D) * a.ldt + rowbase + q0 : nullptr, a.ldt,
                                             min(32, S - q0));
         }
+#ifdef MMU_ATTN_STAMP
+        {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores have left
+            const unsigned long long q_end = stamp_now();
+            if (threadIdx.x == 192 && blockIdx.x < 16384) {  // dQ kernel, last wave: second half of the forward's slots
+                unsigned long long* w = g_fwd_stamps + 8 * (size_t)blockIdx.x;
+                w[0] = nblk; w[1] = qs_wait; w[2] = qs_stage; w[3] = qs_comp; w[4] = q_loop - q_start;
+                w[5] = q_end - q_loop_end; w[6] = q_end - q_start; w[7] = 1;
+            }
+        }
+#endif
         return;
     }
     if (qvalid) {

@@ -2,6 +2,7 @@
 buffer of their own; the real library has no stamp; the diagnostic build's run time is not quoted, only its shares).
   python tools/attn_stamps.py [B]          eight-wave kernel: prologue, tile sweep, loop-top waits, epilogue per workgroup
   python tools/attn_stamps.py --dkdv4 [B]  persistent four-wave kernel: per step (body, waits), per item (epilogue parts)
+  python tools/attn_stamps.py --dq [B]     dQ kernel: prologue, per block (loop-top wait, staging issue, compute), epilogue
   python tools/attn_stamps.py --fwd [B]    forward kernel: per 64-key block of a workgroup's last wave: loop-top wait, staging
                                            issue, QK^T until the row max, softmax + O rescale, P V issue
 ATTN_STAMP_LIB=<path> selects another diagnostic build, e.g. one made with -DDKDV4_EXP=<bits> (timing experiments that
@@ -34,6 +35,28 @@ hip.attn_fwd(qkv[:, :HD], qkv[:, HD:2*HD], qkv[:, 2*HD:], o, lse, None, B, S, H,
 for _ in range(3):
     hip.attn_bwd(qkv[:, :HD], qkv[:, HD:2*HD], qkv[:, 2*HD:], o, lse, None, do, delta, dqkv[:, :HD], dqkv[:, HD:2*HD], dqkv[:, 2*HD:], B, S, H, D, sc, True)
 torch.cuda.synchronize()
+if "--dq" in sys.argv:
+    # dQ kernel, last wave of every workgroup (it overwrites the forward's stamp slots: the backward runs after it):
+    # [blocks, loop-top waits, staging issue, block compute, prologue (entry -> loop), epilogue (loop end -> stores retired), total]
+    L.mmu_debug_read_fwd_stamps.argtypes = [C.c_void_p, C.c_int]; L.mmu_debug_read_fwd_stamps.restype = C.c_int
+    n = min(16384, 9 * H * B)
+    buf = (C.c_ulonglong * (8 * n))()
+    assert L.mmu_debug_read_fwd_stamps(buf, n) == 0
+    rows = [tuple(buf[8*i:8*i+8]) for i in range(n)]
+    rows = [r for r in rows if r[0] > 0 and r[7] == 1]
+    by = {}
+    for r in rows: by.setdefault(r[0], []).append(r)
+    print(f"dQ kernel, {len(rows)} workgroups, wave 3 of each; medians in shader-clock ticks")
+    print("blocks  wgs | workgroup total = prologue + blocks x (wait + stage + compute) + epilogue")
+    for nb in sorted(by):
+        g_ = by[nb]
+        med = lambda f: statistics.median(f(x) for x in g_)
+        print(f"{nb:5d} {len(g_):5d} | {med(lambda x: x[6]):8.0f} = {med(lambda x: x[4]):6.0f} + {nb} x ({med(lambda x: x[1]/x[0]):5.0f} + {med(lambda x: x[2]/x[0]):5.0f} + "
+              f"{med(lambda x: x[3]/x[0]):6.0f}) + {med(lambda x: x[5]):6.0f}")
+    tot = sum(x[6] for x in rows)
+    sh = lambda k: 100 * sum(x[k] for x in rows) / tot
+    print("shares of that wave's time: prologue %.1f%%, loop-top waits %.1f%%, staging issue %.1f%%, block compute %.1f%%, epilogue %.1f%%" % (sh(4), sh(1), sh(2), sh(3), sh(5)))
+    sys.exit(0)
 if "--fwd" in sys.argv:
     # forward kernel, last wave of every workgroup: [blocks, loop-top wait, stage issue, QK^T -> row max, softmax + rescale,
     # P V issue, total, masked blocks] in s_memtime ticks
