@@ -302,6 +302,9 @@ def main():
                          "stream for --squat-ms, standing in for RCCL's all-reduce kernels (tests/c_abi/squatter.hip)")
     ap.add_argument("--squat-ms", type=float, default=80.0)
     ap.add_argument("--no-fuse", action="store_true")
+    ap.add_argument("--no-merge-ga", action="store_true",
+                    help="A/B: walk the gradient-accumulation micro-batches one by one (round-3 behaviour); default: micro-batches "
+                         "that fit HBM together run as ONE concatenated forward/backward (ForgetEngine._groups)")
     ap.add_argument("--full-logits", action="store_true",
                     help="A/B: every forward materialises all logits (round-2 behaviour); default: forwards of which only "
                          ".loss is read run final norm + lm_head + CE on the supervised rows")
@@ -363,7 +366,8 @@ def main():
                                  loss_args={"fuse_pairs": not args.no_fuse, "loss_only_head": not args.full_logits})
     fcfg = ForgetConfig(batch_size=args.micro_batch, gradient_accumulation_steps=args.grad_accum)
     eng = ForgetEngine(model, tr, fcfg, total_steps=args.steps + args.warmup + 1, warmup_steps=1,
-                       transposed_weights=not args.no_wt, optimizer=args.optim, dp_mode=args.dp_mode)
+                       transposed_weights=not args.no_wt, optimizer=args.optim, dp_mode=args.dp_mode,
+                       merge_ga=not args.no_merge_ga)
 
     if args.squat_workgroups:
         import ctypes
@@ -439,6 +443,7 @@ def main():
     # The same step at the REFERENCE's default per-device batch (2 pairs x GA 4, config/mm/forget.yaml:14-15) on the same
     # model / optimiser state, reported beside the headline (whose micro-batch is sized for 288 GB): 1 warm-up + 3 steps.
     ref_batch = None
+    headline_groups = list(eng.last_groups)
     if world == 1 and not args.text_only and args.model != "tiny" and B != 2 and not args.no_reference_batch:
         rb = [bench_batch(cfg, 2, seed=4321 + i, splits=splits, device=dev) for i in range(GA)]
         eng.step(rb)
@@ -508,11 +513,13 @@ def main():
                        "micro_batch_pairs_per_gpu": B,
                        "grad_accum": GA, "global_batch": world * B * GA, "seq_len": S, "parallelism": f"dp{world}",
                        "paired_fusion": not args.no_fuse,
+                       # micro-batches evaluated per forward/backward: [1, 1, 1, 1] = the loop, [4] = one merged sweep
+                       "ga_groups": headline_groups,
                        "optimizer": ("AdamW fp32 moments" if args.optim == "adamw" else "AdamW block-wise 8-bit moments") + ", clip 1.0",
                        "lora_r": args.lora_r,
                        "keep_act_t": model.keep_act_t,
                        "reference_batch_value": (None if ref_batch is None else
-                                                 {"micro_batch_pairs_per_gpu": 2, "grad_accum": GA,
+                                                 {"micro_batch_pairs_per_gpu": 2, "grad_accum": GA, "ga_groups": list(eng.last_groups),
                                                   "samples_per_s": round(ref_batch, 4),
                                                   "step_frac_of_mfma_peak": round(ref_batch * fps / PEAK_BF16, 4)}),
                        "decoder_layers": cfg.text.num_layers},

@@ -200,6 +200,14 @@ int mmu_scatter_rows_bf16(const void* src, const long long* rows, void* dst, lon
 int mmu_seq_ce_stats(const void* logits, int ldv, const long long* labels, int n_seq, int S, int V, float* lse_scratch,
                      float* row_scratch, float* out, void* stream);
 
+/* logits2probs (mm/trainer_utils.py:16-21) for callers that use the helper by name: out [M,V] fp32 = log_softmax(logits)
+ * (log_ != 0) or softmax(logits) over V, lse [M] kept for the backward; mmu_logprobs_bwd turns an upstream gradient
+ * g [M,V] fp32 into dlogits bf16.  (The loss branches of mm/trainer.py never call these: mmu_rowloss_* read the logits
+ * once and materialise nothing.) */
+int mmu_logprobs_fwd(const void* logits, int ldv, float* out, float* lse, int M, int V, int log_, void* stream);
+int mmu_logprobs_bwd(const void* logits, int ldv, const float* lse, const float* g, void* dlogits, int ldd, int M, int V,
+                     int log_, void* stream);
+
 /* 1 forces the streaming row-loss kernel (student / teacher rows walked twice); default 0: rows of V <= 32768 logits are
  * held in registers and cross HBM once (same arithmetic, different summation order).  A/B and test switch. */
 int mmu_rowloss_set_streaming(int on);

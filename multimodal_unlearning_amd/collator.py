@@ -130,7 +130,8 @@ def finalize_on_device(batch: dict, device) -> dict:
         elif torch.is_tensor(v):
             out[k] = v.to(device, non_blocking=True)
             if k in ("attention_mask", "labels") and v.device.type == "cpu":
-                out[k]._mmu_host = v  # lets the model see padding / supervised rows without a device sync (trainer.to_device)
+                from .llava import attach_host
+                attach_host(out[k], v)  # lets the model see padding / supervised rows without a device sync (trainer.to_device)
         else:
             out[k] = v
     return out

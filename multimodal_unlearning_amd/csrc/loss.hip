@@ -619,6 +619,69 @@ __global__ __launch_bounds__(256) void seq_stats_kernel(const float* __restrict_
         out[seq * 3 + 2] = cu;
     }
 }
+
+// logits2probs (mm/trainer_utils.py:16-21) as a materialising kernel, for callers that use the helper by name: out[row] =
+// log_softmax(logits[row]) (log_ != 0) or softmax(logits[row]), fp32 like the reference's autocast path; lse[row] is kept
+// for the backward.  One block per row: one walk for the log-sum-exp, one for the output (the second comes from L2).
+__global__ __launch_bounds__(256) void logprobs_fwd_kernel(const bf16* __restrict__ logits, int ldv, float* __restrict__ out,
+                                                           float* __restrict__ lse, int V, int log_) {
+    __shared__ float scratch[8];
+    const int row = blockIdx.x;
+    const bf16* lr = logits + (size_t)row * ldv;
+    const float l = block_lse(lr, V, scratch);
+    if (threadIdx.x == 0) lse[row] = l;
+    float* orow = out + (size_t)row * V;
+    const int nch = V >> 3;
+    for (int ch = threadIdx.x; ch < nch; ch += 256) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(lr + ch * 8);
+        f32x4 a, b;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float x0 = bf2f(v[j]) - l, x1 = bf2f(v[4 + j]) - l;
+            a[j] = log_ ? x0 : __expf(x0);
+            b[j] = log_ ? x1 : __expf(x1);
+        }
+        *reinterpret_cast<f32x4*>(orow + ch * 8) = a;
+        *reinterpret_cast<f32x4*>(orow + ch * 8 + 4) = b;
+    }
+}
+
+// backward of the above for an upstream gradient g [M,V] fp32: log-softmax: dx = g - p * sum_v g; softmax: dx = p * (g -
+// sum_v g p), p = exp(x - lse).  dlogits bf16.
+__global__ __launch_bounds__(256) void logprobs_bwd_kernel(const bf16* __restrict__ logits, int ldv, const float* __restrict__ lse,
+                                                           const float* __restrict__ g, bf16* __restrict__ dlogits, int ldd,
+                                                           int V, int log_) {
+    __shared__ float scratch[4];
+    const int row = blockIdx.x;
+    const bf16* lr = logits + (size_t)row * ldv;
+    const float* gr = g + (size_t)row * V;
+    const float l = lse[row];
+    const int nch = V >> 3;
+    float acc = 0.f;
+    for (int ch = threadIdx.x; ch < nch; ch += 256) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(gr + ch * 8), b = *reinterpret_cast<const f32x4*>(gr + ch * 8 + 4);
+        if (log_) {
+            acc += (a[0] + a[1]) + (a[2] + a[3]) + (b[0] + b[1]) + (b[2] + b[3]);
+        } else {
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(lr + ch * 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc += a[j] * __expf(bf2f(v[j]) - l) + b[j] * __expf(bf2f(v[4 + j]) - l);
+        }
+    }
+    const float tot = block_sum<4>(acc, scratch);
+    bf16* dr = dlogits + (size_t)row * ldd;
+    for (int ch = threadIdx.x; ch < nch; ch += 256) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(lr + ch * 8);
+        const f32x4 a = *reinterpret_cast<const f32x4*>(gr + ch * 8), b = *reinterpret_cast<const f32x4*>(gr + ch * 8 + 4);
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float p = __expf(bf2f(v[j]) - l), gj = j < 4 ? a[j] : b[j - 4];
+            o[j] = f2bf(log_ ? gj - p * tot : p * (gj - tot));
+        }
+        *reinterpret_cast<bf16x8*>(dr + ch * 8) = o;
+    }
+}
 }  // namespace
 
 static int g_rowloss_streaming = 0;
@@ -762,6 +825,23 @@ extern "C" int mmu_seq_ce_stats(const void* logits, int ldv, const long long* la
                        lse_scratch, row_scratch, n_seq * S, V, S, 1);
     MMU_CHECK_LAUNCH();
     hipLaunchKernelGGL(seq_stats_kernel, dim3(n_seq), dim3(256), 0, (hipStream_t)stream, row_scratch, labels, S, V, out);
+    MMU_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mmu_logprobs_fwd(const void* logits, int ldv, float* out, float* lse, int M, int V, int log_, void* stream) {
+    if (M <= 0 || (V & 7) || (ldv & 7)) return -1;
+    hipLaunchKernelGGL(logprobs_fwd_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (const bf16*)logits, ldv, out, lse, V,
+                       log_);
+    MMU_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mmu_logprobs_bwd(const void* logits, int ldv, const float* lse, const float* g, void* dlogits, int ldd, int M,
+                                int V, int log_, void* stream) {
+    if (M <= 0 || (V & 7) || (ldv & 7) || (ldd & 7)) return -1;
+    hipLaunchKernelGGL(logprobs_bwd_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (const bf16*)logits, ldv, lse, g,
+                       (bf16*)dlogits, ldd, V, log_);
     MMU_CHECK_LAUNCH();
     return 0;
 }

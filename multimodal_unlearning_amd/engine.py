@@ -226,7 +226,8 @@ class ForgetEngine:
 
     def __init__(self, model, trainer, cfg: ForgetConfig, total_steps: int = 1000, warmup_steps: int = 0,
                  group=None, transposed_weights: bool = True, force_collectives: bool = False,
-                 optimizer: str = "adamw", dp_mode: str = "allreduce", bucket_elems: int = 1 << 27):
+                 optimizer: str = "adamw", dp_mode: str = "allreduce", bucket_elems: int = 1 << 27,
+                 merge_ga: bool = True, merge_tokens="auto"):
         from . import hip  # HIP optimiser kernels; fails loudly when the library is missing
 
         self.hip = hip
@@ -278,6 +279,9 @@ class ForgetEngine:
             self.nodecay.append(torch.tensor(rel, device=dev, dtype=torch.int64).reshape(-1, 2) if rel else None)
         self.sumsq = torch.zeros(hip.SUMSQ_FLOATS, device=dev, dtype=torch.float32)  # [0] = |g|^2, rest scratch
         self.opt_step = 0
+        # gradient-accumulation micro-batches are evaluated as one concatenated batch where shapes, loss and HBM allow
+        # (`_groups`); merge_tokens: "auto" = from free HBM, or an explicit cap on positions per forward
+        self.merge_ga, self.merge_tokens, self.last_groups = merge_ga, merge_tokens, []
         # exposed gradient-exchange time: the stretch of the compute stream between the end of the last backward sweep
         # and the completion of the last collective (device events; read by bench.py, never synchronised here)
         self.time_exchange = False
@@ -315,20 +319,73 @@ class ForgetEngine:
         dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=self.group)  # same bits on every rank
         self.sumsq[0:1].copy_(acc)
 
+    # ---------------------------------------------------------------------------------- merged micro-batches
+    def _tokens_of(self, mb) -> int:
+        """Sequence positions one micro-batch sends through the student (every split, every row)."""
+        splits = mb.values() if isinstance(mb, dict) else mb
+        n = 0
+        for sp in splits:
+            ids = sp["input_ids"] if isinstance(sp, dict) else sp[0]
+            n += ids.numel()
+        return n
+
+    def _token_budget(self) -> int:
+        """How many sequence positions ONE forward/backward may hold, from the HBM that is free right now (the caching
+        allocator's idle blocks count as free) and the model's estimate of what a position keeps alive."""
+        if self.merge_tokens != "auto":
+            return int(self.merge_tokens)
+        per_tok = getattr(self.model, "activation_bytes_per_token", None)
+        if per_tok is None or not self.grad.is_cuda:
+            return 0
+        dev = self.grad.device
+        free, _ = torch.cuda.mem_get_info(dev)
+        free += torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+        return int(0.8 * free / per_tok())
+
+    def _groups(self, micro_batches):
+        """[(inputs, g)]: runs of consecutive micro-batches that are evaluated as ONE concatenated batch (g of them), so
+        that the reference's small per-device batch (2 pairs x GA 4, config/mm/forget.yaml:14-15) reaches the GEMMs as
+        M = g * B * S rows instead of g launches of B * S.  Rows never interact and every loss term is a mean over
+        equal-sized sets, a per-segment token mean or a sum (MMTrainerForgetting.merge_micro_batches), so loss and
+        gradients are those of the loop up to summation order.  A run ends where the HBM budget or the shapes say so; a
+        run of one is the plain loop."""
+        merge = getattr(self.trainer, "merge_micro_batches", None)
+        if not self.merge_ga or merge is None or len(micro_batches) < 2:
+            return [(mb, 1) for mb in micro_batches]
+        budget = self._token_budget()
+        out, i, n = [], 0, len(micro_batches)
+        while i < n:
+            j, tok = i + 1, self._tokens_of(micro_batches[i])
+            while j < n and tok + self._tokens_of(micro_batches[j]) <= budget:
+                tok += self._tokens_of(micro_batches[j])
+                j += 1
+            merged = merge(self.model, micro_batches[i:j]) if j - i > 1 else None
+            if merged is None:
+                out += [(mb, 1) for mb in micro_batches[i:j]]
+            else:
+                out.append((merged, j - i))
+            i = j
+        return out
+
     def step(self, micro_batches: List[Dict], sync_loss: bool = False) -> StepStats:
         ga = len(micro_batches)
         model = self.model
         total = None
-        for i, mb in enumerate(micro_batches):
-            last = i == ga - 1
+        groups = self._groups(micro_batches)
+        self.last_groups = [g for _, g in groups]
+        for i, (mb, g) in enumerate(groups):
+            last = i == len(groups) - 1
             hook = self.reducer.mark_final if (last and self.reducer.enabled) else None
             if last and self.exchange_start_callback is not None:
                 hook = self._with_start_callback(hook)
             model.grad_ready_hook = hook
             model.live_sweeps = 0
-            loss = self.trainer.compute_loss(model, mb)
-            (loss / ga).backward()
-            d = loss.detach().float()
+            if g > 1:  # mean of the g micro-batch losses, from one forward/backward over their concatenation
+                loss = self.trainer.compute_loss(model, mb, _merge=g)
+            else:
+                loss = self.trainer.compute_loss(model, mb)
+            (loss / ga if g == 1 else loss * (g / ga)).backward()
+            d = loss.detach().float() * g
             total = d if total is None else total + d
         model.grad_ready_hook = None
         ev = None

@@ -26,8 +26,30 @@ LOG_KEYS = ("average_perturb_loss", "avg_paraphrased_loss", "truth_ratio", "para
 
 
 def sequence_ce_stats(model, split: Dict[str, torch.Tensor]) -> torch.Tensor:
-    """float32 [n, 3] on the device: per sequence {sum_t CE, #shifted targets != -100, #labels != -100}."""
+    """float32 [n, 3] on the device: per sequence {sum_t CE, #shifted targets != -100, #labels != -100}.
+
+    The pass reads CE on supervised positions only, so a model that can (`LlavaHIP.compact_logits`) runs the final norm
+    and the lm_head on those rows alone — [n * cap, V] instead of [n * S, V] logits — and the CE kernels take the
+    compact rows with their own (already shifted) targets.  Same values as the full pass up to summation order.  Foreign
+    models, and ids that still carry ONE <image> id per picture (transformers 4.45.1 expands them inside the model, so the
+    logits are longer than the ids and `remove_image_tokens` has work to do), keep the full-logits path."""
     dev = next(model.parameters()).device
+    labels = split["labels"]
+    if hasattr(model, "compact_logits"):
+        from .llava import host_of
+
+        with torch.no_grad():
+            lc, tgt, cap = model.compact_logits(**{k: v for k, v in split.items()})
+        n = labels.shape[0]
+        M, V = lc.shape
+        lse = torch.empty(M, device=dev, dtype=torch.float32)
+        lrow = torch.empty(M, device=dev, dtype=torch.float32)
+        hip.ce_fwd(lc, tgt, lse, lrow, cap, shift=False)
+        out = torch.empty(3, n, device=dev, dtype=torch.float32)
+        hip.seg_reduce(lrow, tgt, cap, M, V, cap, False, out[0], out[1])     # CE sums, #shifted targets
+        host = host_of(labels, fetch=True)                                    # #labels != -100 of the UNSHIFTED row:
+        out[2].copy_((host != -100).sum(dim=1).to(torch.float32), non_blocking=True)  # index bookkeeping on the host view
+        return out.t().contiguous()
     split = {k: v.to(dev) for k, v in split.items()}
     with torch.no_grad():
         logits = model(**{k: v for k, v in split.items() if k != "labels"}).logits

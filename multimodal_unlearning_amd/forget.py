@@ -278,13 +278,23 @@ def run(rc: ForgetRunConfig):
     lora = LoraSpec(r=rc.lora_r, alpha=rc.lora_alpha) if use_lora else None
     need_teacher = bool(rc.l1_lambda or rc.l0_lambda) or tu.loss_needs_teacher(lt)
     params = extra = None
-    if _has_checkpoint(rc.model_path):
+    # What model_path holds is decided ONCE, by rank 0, before any rank can have written there (the merge below rewrites the
+    # directory): a slower rank that looked for itself could find the adapter already retired, skip the merge, train on
+    # unmerged weights and miss the barriers of the branch.
+    has_ckpt = _has_checkpoint(rc.model_path)
+    has_adapter = has_ckpt and os.path.exists(os.path.join(rc.model_path, "adapter_config.json"))
+    if world > 1:
+        import torch.distributed as dist
+
+        seen = [has_ckpt, has_adapter]
+        dist.broadcast_object_list(seen, src=0)
+        has_ckpt, has_adapter = seen
+    if has_ckpt:
         log("Loading from checkpoint")
         params, extra = load_pretrained(cfg, rc.model_path, return_extra=True)
     else:
         log(f"no safetensors under model_path={rc.model_path!r}: RANDOM-INIT weights of {cfg.name} (seed {rc.seed})")
-    adapter_cfg = os.path.join(rc.model_path or "", "adapter_config.json")
-    if params is not None and os.path.exists(adapter_cfg):
+    if has_adapter:
         # mm/forget.py:100-113 "Loading after merge and unload": model_path holds a LoRA run (this repo saves the base
         # weights next to the peft-layout adapter; the reference fetches the base from the hub).  Fold the adapter into
         # the base, keep the result as the new full checkpoint of that directory ("so that we can again do PEFT style
@@ -292,21 +302,26 @@ def run(rc: ForgetRunConfig):
         from .checkpoint import load_adapter
 
         log("Loading after merge and unload")
-        conf = json.load(open(adapter_cfg))
+        conf = json.load(open(os.path.join(rc.model_path, "adapter_config.json")))
         tmp = LlavaHIP(cfg, params, device=dev, lora=LoraSpec(r=int(conf["r"]), alpha=float(conf["lora_alpha"])), trainable=False)
         state, _, _ = load_adapter(cfg, rc.model_path, [n[:-len(".weight")] for n in tmp.lora])
         tmp.load_lora_state_(state)
         tmp.merge_lora_()
         params = {k: v.detach().clone() for k, v in tmp.w.items()}  # stays on the device (bf16): no 4-byte host copy of 7B
+        if world > 1:
+            dist.barrier()  # every rank has finished READING model_path (weights and adapter) before rank 0 rewrites it
         if rank == 0:
-            save_pretrained(cfg, tmp.w, rc.model_path, extra=extra)
+            # written under temporary names and moved into place file by file: a reader never sees a half-written shard
+            stage = os.path.join(rc.model_path, ".merge_tmp")
+            save_pretrained(cfg, tmp.w, stage, extra=extra)
+            for f in sorted(os.listdir(stage)):
+                os.replace(os.path.join(stage, f), os.path.join(rc.model_path, f))
+            os.rmdir(stage)
             for f in ("adapter_config.json", "adapter_model.safetensors"):
                 os.replace(os.path.join(rc.model_path, f), os.path.join(rc.model_path, f + ".merged"))
         del tmp
         if world > 1:
-            import torch.distributed as dist
-
-            dist.barrier()
+            dist.barrier()  # the directory is whole again before anyone goes on (all ranks took this branch: has_adapter is rank 0's)
     model = LlavaHIP(cfg, params, device=dev, lora=lora, seed=rc.seed, init="device" if params is None else "numpy")
     teacher = None
     if need_teacher:  # the reference loads the same checkpoint a second time (mm/forget.py:91-99)

@@ -78,6 +78,8 @@ SIGNATURES = {
     "mmu_scatter_rows_bf16": [_vp, _vp, _vp, _ll, _i, _i, _vp],
     "mmu_rowloss_set_streaming": [_i],
     "mmu_seq_ce_stats": [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "mmu_logprobs_fwd": [_vp, _i, _vp, _vp, _i, _i, _i, _vp],
+    "mmu_logprobs_bwd": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "mmu_red_scratch_floats": [],
     "mmu_mse_fwd": [_vp, _vp, _vp, _ll, _i, _vp, _vp],
     "mmu_mse_bwd": [_vp, _vp, _vp, _ll, _i, _vp, _vp, _vp],
@@ -562,6 +564,23 @@ def seq_ce_stats(logits, labels):
     _check(load().mmu_seq_ce_stats(_p(logits), V, _p(labels), n, S, V, _p(scr[0]), _p(scr[1]), _p(out), _stream()),
            "mmu_seq_ce_stats")
     return out
+
+
+def logprobs_fwd(logits2d, out, lse, log=True):
+    """out [M,V] fp32 = log_softmax / softmax of logits2d [M,V] bf16 (mm/trainer_utils.py:16-21), lse [M] fp32."""
+    _bf16c(logits2d)
+    M, V = logits2d.shape
+    assert logits2d.is_contiguous() and out.dtype == torch.float32 and out.is_contiguous() and out.shape == (M, V)
+    assert lse.dtype == torch.float32 and lse.numel() == M
+    _check(load().mmu_logprobs_fwd(_p(logits2d), V, _p(out), _p(lse), M, V, int(bool(log)), _stream()), "mmu_logprobs_fwd")
+
+
+def logprobs_bwd(logits2d, lse, g, dlogits, log=True):
+    _bf16c(logits2d, dlogits)
+    M, V = logits2d.shape
+    assert g.dtype == torch.float32 and g.is_contiguous() and g.shape == (M, V) and dlogits.is_contiguous()
+    _check(load().mmu_logprobs_bwd(_p(logits2d), V, _p(lse), _p(g), _p(dlogits), V, M, V, int(bool(log)), _stream()),
+           "mmu_logprobs_bwd")
 
 
 # ------------------------------------------------------------------------------------------------- RMU terms

@@ -73,6 +73,48 @@ def _align8(n):
 
 
 # --------------------------------------------------------------------------------------------------------
+# host views of the small integer tensors (labels, attention masks) the host logic has to look at
+# --------------------------------------------------------------------------------------------------------
+def attach_host(dev_t: torch.Tensor, host_t: torch.Tensor) -> torch.Tensor:
+    """Remember on the device tensor the host tensor it was copied from (collator output), with both version counters:
+    an in-place edit of either side afterwards (a host loop masking extra tokens, a reused host buffer) invalidates the
+    shortcut instead of silently selecting rows / dropping the key mask from stale data."""
+    dev_t._mmu_host = (host_t, host_t._version, dev_t._version)
+    return dev_t
+
+
+def host_of(t: Optional[torch.Tensor], fetch: bool = False) -> Optional[torch.Tensor]:
+    """Host copy of a [B, S] label / mask tensor: the tensor itself when it lives on the host, the tensor recorded by
+    `attach_host` while neither side has been written since, else None — or, with fetch=True, a fresh device->host copy
+    (ONE sync) that is recorded on the tensor object, so a batch that stays in HBM and is stepped over repeatedly
+    (bench.py) pays it once."""
+    if t is None:
+        return None
+    if t.device.type == "cpu":
+        return t
+    rec = getattr(t, "_mmu_host", None)
+    if rec is not None:
+        host, hv, dv = rec
+        if host._version == hv and t._version == dv:
+            return host
+    if not fetch:
+        return None
+    host = t.detach().cpu()
+    attach_host(t, host)
+    return host
+
+
+def cat_with_host(tensors, dim: int = 0) -> torch.Tensor:
+    """torch.cat that carries the host views along (paired fusion, merged micro-batches): the concatenation is a new
+    tensor object every call, so whatever the parts already know about their contents must travel with it."""
+    out = torch.cat(list(tensors), dim=dim)
+    if out.device.type != "cpu":
+        hosts = [host_of(t, fetch=True) for t in tensors]
+        attach_host(out, torch.cat(hosts, dim=dim))
+    return out
+
+
+# --------------------------------------------------------------------------------------------------------
 # loss autograd functions (kernels in csrc/loss.hip)
 # --------------------------------------------------------------------------------------------------------
 class _SegCE(torch.autograd.Function):
@@ -100,6 +142,13 @@ class _SegCE(torch.autograd.Function):
         S, seg_rows, normalize, shift, grad_in_place = ctx.meta
         # the logits of a loss-only forward belong to this edge alone: their gradient overwrites them in place (the
         # kernel reads every element before the same lane writes it) instead of taking another [rows, V] buffer
+        if grad_in_place:
+            # the kernel writes through the C ABI, which autograd's version counters do not see: a second backward through
+            # this edge (retain_graph=True) would differentiate the gradient instead of the logits
+            if getattr(ctx, "consumed", False):
+                raise RuntimeError("backward through a loss-only forward twice: its logits were overwritten by their "
+                                   "gradient (loss_args={'loss_only_head': False} keeps them)")
+            ctx.consumed = True
         dl = logits2d if grad_in_place else torch.empty_like(logits2d)
         hip.ce_bwd(logits2d, labels, lse, g.contiguous().float(), cnts, seg_rows, normalize, dl, S, shift=shift)
         return dl, None, None, None, None, None, None
@@ -264,10 +313,12 @@ class LlavaHIP(nn.Module):
         # engine then reduces what no hook covered).
         self.live_sweeps = 0
         self.capture_layer: Optional[int] = None
-        self._rows_cache: list = []
-        self._mask_cache: list = []
         self._derived_at = -1
         self.position_ids_mode = "arange"  # or "from_mask" (transformers 4.45.1 left-padding positions); see _positions
+        # > 1 while the plug-in evaluates several gradient-accumulation micro-batches as ONE concatenated batch
+        # (MMTrainerForgetting.compute_loss(..., _merge=g)): `.loss` is then the mean over the g equal row segments of each
+        # segment's own mean CE — what the host loop would have averaged — instead of one mean over all tokens
+        self.loss_segments = 1
         if self.lora:
             self.init_lora_(seed)
 
@@ -610,6 +661,19 @@ class LlavaHIP(nn.Module):
                 self.g[name] = self._grad_flat[off:off + math.prod(shape)].view(shape)
         return self._grad_flat
 
+    def activation_bytes_per_token(self) -> int:
+        """Upper estimate of the HBM one sequence position keeps alive through a training forward + backward (DESIGN.md
+        §3): per decoder layer the saved h, a, h2 (2d each), q|k|v (6d), gate|up (4I) and, with keep_act_t, act^T (2I);
+        the backward's working set (dgu, dgu^T, dact, dqkv, dqkv^T, y^T, dy, dh, dh2); student + teacher logits, their
+        gradient and row statistics.  The step loop sizes merged micro-batches with it (ForgetEngine._groups)."""
+        t = self.cfg.text
+        d, I, V, L = t.hidden_size, t.intermediate_size, t.vocab_size, t.num_layers
+        per_layer = 12 * d + 4 * I + (2 * I if self.keep_act_t else 0)
+        if self.lora:
+            per_layer += 2 * I + 2 * d  # act and the x A^T products kept for the adapter wgrads
+        work = 12 * I + 24 * d
+        return L * per_layer + work + 8 * V
+
     # ----------------------------------------------------------------------------------------- forward
     # model(**split, loss_only=True) is understood (the plug-in asks before passing the keyword to a foreign model)
     supports_loss_only = True
@@ -621,23 +685,26 @@ class LlavaHIP(nn.Module):
         the CE kernels and their backward run on the supervised rows only (`supervised_rows`).  Same value and gradients
         as `forward(...).loss` up to summation order (tests/test_model_gpu.py::test_loss_only_matches_full_logits); at
         the headline workload 256 of 1088 positions per sequence are supervised: -76 % of the lm_head's three GEMMs."""
+        B = input_ids.shape[0]
+        assert B % n_segments == 0
+        lc, tgt, cap = self.compact_logits(input_ids, attention_mask, pixel_values, labels, position_ids)
+        return _SegCE.apply(lc, tgt, cap, (B // n_segments) * cap, True, False, True)
+
+    def compact_logits(self, input_ids, attention_mask=None, pixel_values=None, labels=None, position_ids=None):
+        """Logits of the supervised positions only: (logits [B * cap, V] bf16 attached to autograd, targets [B * cap] int64
+        UNshifted — slot r of a sequence holds the position whose next label is targets[r], -100 in padding slots —, cap =
+        slots per sequence).  The final norm and the lm_head run on those rows alone (`supervised_rows`)."""
         dev = self.device
         ids = input_ids.to(dev, dtype=torch.int64).contiguous()
         B, S = ids.shape
-        assert B % n_segments == 0
-        # device-resident label tensors that are stepped over repeatedly (bench.py) pay the sync of the row selection
-        # once: the cache holds the tensor OBJECT (so its memory cannot be recycled under the entry) and its version
-        hit = None
-        for t_, ver, val in self._rows_cache:
-            if t_ is labels and ver == labels._version:
-                hit = val
-                break
+        # the row selection is index arithmetic on the HOST view of the labels (collator output carries one; a
+        # device-resident tensor fetches it once and keeps it, see host_of); the result is remembered on the tensor
+        # object together with its version, so stepping over the same batch again costs nothing
+        rec = getattr(labels, "_mmu_rows", None)
+        hit = rec[1] if (rec is not None and rec[0] == labels._version) else None
         if hit is None:
-            host = getattr(labels, "_mmu_host", None)  # host copy of the same labels: no device sync for the row count
-            hit = supervised_rows(labels if host is None else host, self.cfg.text.vocab_size, dev)
-            if labels.is_cuda and host is None:
-                self._rows_cache.append((labels, labels._version, hit))
-                del self._rows_cache[:-16]
+            hit = supervised_rows(host_of(labels, fetch=True), self.cfg.text.vocab_size, dev)
+            labels._mmu_rows = (labels._version, hit)
         rows, tgt, cap = hit
         kmask = self._kmask(attention_mask)
         pos = self._positions(position_ids, attention_mask, B, S)
@@ -649,7 +716,7 @@ class LlavaHIP(nn.Module):
         else:
             with torch.no_grad():
                 lc, _ = self._forward_impl(ids, kmask, pix, pos, save=False, rows=rows)
-        return _SegCE.apply(lc, tgt, cap, (B // n_segments) * cap, True, False, True)
+        return lc, tgt, cap
 
     def _kmask(self, attention_mask):
         """int32 key mask for the attention kernels, or None when nothing is padded (the kernels then skip the per-block
@@ -659,31 +726,24 @@ class LlavaHIP(nn.Module):
         so batches that stay in HBM and are stepped over repeatedly pay nothing afterwards."""
         if attention_mask is None:
             return None
-        if attention_mask.device.type == "cpu":
-            return None if bool(attention_mask.all()) else attention_mask.to(self.device, dtype=torch.int32).contiguous()
-        host = getattr(attention_mask, "_mmu_host", None)  # the collator's tensor this one was copied from (trainer.to_device)
-        if host is not None:
-            return None if bool(host.all()) else attention_mask.to(dtype=torch.int32).contiguous()
-        if os.environ.get("MMU_NO_MASK_INSPECT", "0") == "1":  # A/B switch: hand every device-resident mask to the kernels
-            return attention_mask.to(dtype=torch.int32).contiguous()
-        for t_, ver, full in self._mask_cache:
-            if t_ is attention_mask and ver == attention_mask._version:
-                break
-        else:
-            full = bool(attention_mask.all())
-            self._mask_cache.append((attention_mask, attention_mask._version, full))
-            del self._mask_cache[:-32]
-        return None if full else attention_mask.to(dtype=torch.int32).contiguous()
+        if attention_mask.device.type != "cpu" and os.environ.get("MMU_NO_MASK_INSPECT", "0") == "1":
+            return attention_mask.to(dtype=torch.int32).contiguous()  # A/B switch: every device-resident mask goes to the kernels
+        full = bool(host_of(attention_mask, fetch=True).all())
+        return None if full else attention_mask.to(self.device, dtype=torch.int32).contiguous()
 
     def forward(self, input_ids=None, attention_mask=None, pixel_values=None, labels=None, position_ids=None,
                 loss_only: bool = False, **_unused):
+        g = self.loss_segments
         if loss_only and labels is not None and self.capture_layer is None:
-            loss = self.ce_losses(input_ids, attention_mask, pixel_values, labels, position_ids)[0]
-            return LlavaOutput(loss=loss, logits=None)
+            ce = self.ce_losses(input_ids, attention_mask, pixel_values, labels, position_ids, n_segments=g)
+            return LlavaOutput(loss=ce[0] if g == 1 else ce.mean(), logits=None)
         logits = self.logits(input_ids, attention_mask, pixel_values, position_ids)
         loss = None
         if labels is not None:
-            loss = causal_lm_loss(logits, labels.to(logits.device))
+            if g == 1:
+                loss = causal_lm_loss(logits, labels.to(logits.device))
+            else:  # merged micro-batches: `.loss` = mean over the micro-batches of each one's own token mean
+                loss = segment_ce_losses(logits, labels.to(logits.device), g).mean()
         hs = None
         if self.capture_layer is not None:
             hs = self._last_capture
@@ -825,6 +885,14 @@ class LlavaHIP(nn.Module):
             dhn = torch.empty_like(h)
             hip.layernorm_bwd(dy1, h, w[p + "ln1.weight"], dh2, dhn, v.layer_norm_eps)
             dh = dhn
+
+    @property
+    def decoder_layers(self):
+        """Handles for `trainer_utils.forward_with_cache(model, inputs, module=model.decoder_layers[i])` — the reference
+        passes `model.language_model.model.layers[i]` there (mm/trainer.py:302-310)."""
+        from .trainer_utils import DecoderLayerHandle
+
+        return [DecoderLayerHandle(i) for i in range(self.cfg.text.num_layers)]
 
     def hidden_states(self, layer: int, input_ids=None, attention_mask=None, pixel_values=None, position_ids=None,
                       **_unused):

@@ -22,7 +22,7 @@ from __future__ import annotations
 import torch
 
 from . import trainer_utils as tu
-from .llava import segment_ce_losses
+from .llava import attach_host, cat_with_host, host_of, segment_ce_losses
 
 _SPLIT_KEYS = ("input_ids", "attention_mask", "pixel_values", "labels")
 
@@ -110,6 +110,24 @@ class _RmuForgetFn(torch.autograd.Function):
         return da, None
 
 
+def _slice_k(v, i):
+    """v[:, i] of a nested [B, K, ...] split tensor, carrying the host view of labels / masks along (a fresh view has
+    none, and looking at it would cost a device sync on every call)."""
+    out = v[:, i]
+    h = host_of(v)
+    if h is not None and out.device.type != "cpu":
+        attach_host(out, h[:, i])
+    return out
+
+
+# losses whose per-micro-batch value is a mean over equal-sized sets (KL batchmean over B*S rows, NPO mean over B*S*V,
+# dpo's mean over sequences), a per-segment token mean (every CE term, through the segmented CE kernel) or a plain sum
+# (entropy, divided by g): the mean over g micro-batches equals ONE evaluation on their concatenation.  rmu (control
+# vector of batch shape, [B,B,H] broadcast) and sku (nested [B,K] split) are evaluated micro-batch by micro-batch.
+_MERGEABLE = ("retain_ft", "grad_ascent", "scrub", "kl", "llmu", "npo", "idk", "eco_ft", "dpo")
+_CE_ONLY = ("retain_ft", "grad_ascent", "grad_diff_forget_ce_retain_ce", "idk", "eco_ft")
+
+
 class MMTrainerForgetting:
     def __init__(self, *args, **kwargs):
         self._pop_forget_kwargs(kwargs)
@@ -130,6 +148,7 @@ class MMTrainerForgetting:
         # MI355X addition: forwards of which only `.loss` is read run the lm_head on the supervised rows (A/B switch)
         self.loss_only_head = bool(self.loss_args.get("loss_only_head", True))
         self.control_vec = None
+        self._merge = 1  # > 1 only inside compute_loss(..., _merge=g)
         self.is_deepspeed_enabled = False
         if tu.loss_needs_teacher(self.loss_type) and self.teacher_model is None:
             raise ValueError(f"forget_loss={self.loss_type} evaluates a frozen teacher: pass teacher_model")
@@ -154,8 +173,50 @@ class MMTrainerForgetting:
             # collator output lives on the host: the device copy remembers it, so the model can look at masks / labels
             # (padding? which rows are supervised?) without a device sync
             if d is not v and k in ("attention_mask", "labels") and v.device.type == "cpu":
-                d._mmu_host = v
+                attach_host(d, v)
             out[k] = d
+        return out
+
+    # ------------------------------------------------------------------------ merged micro-batches (MI355X addition)
+    def can_merge(self, model) -> bool:
+        lt = self.loss_type
+        return hasattr(model, "loss_segments") and (lt in _MERGEABLE or lt.startswith("grad_diff"))
+
+    def merge_micro_batches(self, model, micro_batches, pad_token_id: int = 0):
+        """ONE nested input dict that concatenates the gradient-accumulation micro-batches along the batch dimension, or
+        None when they cannot be evaluated together (different keys / batch sizes, a loss outside `can_merge`).
+        Micro-batches of different sequence length are LEFT-padded to the longest (pad id, mask 0, label -100) for the
+        CE-only losses — padded keys are masked and RoPE scores depend on position differences only; losses that
+        normalise over all B*S rows (KL batchmean, NPO, entropy) need equal shapes, as padding rows would be counted.
+        `compute_loss(model, merged, _merge=len(micro_batches))` then returns the mean of the individual losses."""
+        if len(micro_batches) < 2 or not self.can_merge(model) or not all(isinstance(mb, dict) for mb in micro_batches):
+            return None
+        first = micro_batches[0]
+        if any(mb.keys() != first.keys() for mb in micro_batches):
+            return None
+        out = {}
+        for split in first:
+            parts = [mb[split] for mb in micro_batches]
+            if any(p.keys() != parts[0].keys() for p in parts):
+                return None
+            ids = [p["input_ids"] for p in parts]
+            if any(x.dim() != 2 or x.shape[0] != ids[0].shape[0] for x in ids):
+                return None
+            S = max(x.shape[1] for x in ids)
+            ragged = any(x.shape[1] != S for x in ids)
+            if ragged and (self.loss_type not in _CE_ONLY or "attention_mask" not in parts[0]):
+                return None
+            merged = {}
+            for k in parts[0]:
+                ts = [p[k] for p in parts]
+                if k in ("input_ids", "attention_mask", "labels") and ragged:
+                    fill = {"input_ids": pad_token_id, "attention_mask": 0, "labels": -100}[k]
+                    ts = [t if t.shape[1] == S else torch.cat([t.new_full((t.shape[0], S - t.shape[1]), fill), t], dim=1)
+                          for t in ts]
+                elif any(t.shape[1:] != ts[0].shape[1:] for t in ts):
+                    return None
+                merged[k] = (cat_with_host if k in ("attention_mask", "labels") else torch.cat)(ts, dim=0)
+            out[split] = merged
         return out
 
     # ------------------------------------------------------------------------------------------------
@@ -175,22 +236,21 @@ class MMTrainerForgetting:
     def _paired_ce(self, model, a, b, need_outputs=False):
         """One forward over cat(a, b); returns (ce_a, ce_b, outputs).  When nobody asked for the outputs and the model
         can do it, the head runs on the supervised rows only (LlavaHIP.ce_losses) and `outputs` carries no logits."""
-        cat = {k: torch.cat([a[k], b[k]], dim=0) for k in _SPLIT_KEYS if k in a and k != "labels"}
-        labels = torch.cat([a["labels"], b["labels"]], dim=0)
-        ha, hb = getattr(a["labels"], "_mmu_host", None), getattr(b["labels"], "_mmu_host", None)
-        if ha is not None and hb is not None:
-            labels._mmu_host = torch.cat([ha, hb], dim=0)
-        if "attention_mask" in cat:
-            ma, mb = getattr(a["attention_mask"], "_mmu_host", None), getattr(b["attention_mask"], "_mmu_host", None)
-            if ma is not None and mb is not None:
-                cat["attention_mask"]._mmu_host = torch.cat([ma, mb], dim=0)
+        g = self._merge
+        cat = {k: (cat_with_host if k == "attention_mask" else torch.cat)([a[k], b[k]], dim=0)
+               for k in _SPLIT_KEYS if k in a and k != "labels"}
+        labels = cat_with_host([a["labels"], b["labels"]], dim=0)
         if not need_outputs and getattr(model, "supports_loss_only", False) and self.loss_only_head:
-            ce = model.ce_losses(labels=labels, n_segments=2, **cat)
+            ce = model.ce_losses(labels=labels, n_segments=2 * g, **cat)
             from .llava import LlavaOutput
-            return ce[0], ce[1], LlavaOutput(loss=None, logits=None)
-        out = model(**cat)
-        ce = segment_ce_losses(out.logits, labels.to(out.logits.device), 2)
-        return ce[0], ce[1], out
+            return ce[:g].mean(), ce[g:].mean(), LlavaOutput(loss=None, logits=None)
+        keep, model.loss_segments = getattr(model, "loss_segments", 1), 1
+        try:
+            out = model(**cat)
+        finally:
+            model.loss_segments = keep
+        ce = segment_ce_losses(out.logits, labels.to(out.logits.device), 2 * g)
+        return ce[:g].mean(), ce[g:].mean(), out
 
     def _loss_of(self, model, split, need_outputs=False):
         """`model(**split)` when only `.loss` will be read: models that understand `loss_only=True` (LlavaHIP) skip the
@@ -209,6 +269,17 @@ class MMTrainerForgetting:
         random_inputs = td(dev, inputs["random"]) if "random" in inputs else None
         lt, beta = self.loss_type, self.loss_beta
         outputs = None
+        # `_merge=g`: `inputs` is the concatenation of g gradient-accumulation micro-batches (merge_micro_batches) and the
+        # value returned is the MEAN of the g losses the host loop would have computed one by one
+        g = int(kwargs.get("_merge", 1))
+        if g > 1:
+            if not self.can_merge(model):
+                raise ValueError(f"forget_loss={self.loss_type} cannot evaluate merged micro-batches on this model")
+            self._merge, keep_seg, model.loss_segments = g, model.loss_segments, g
+            try:
+                return self.compute_loss(model, inputs, return_outputs, *args, **{**kwargs, "_merge": 1, "_merged": g})
+            finally:
+                self._merge, model.loss_segments = 1, keep_seg
         # does anybody read the outputs?  (the text trainer calls this method with return_outputs=True for its own
         # bookkeeping and passes what ITS caller asked for in `_need_outputs`)
         need_out = bool(kwargs.get("_need_outputs", return_outputs))
@@ -231,7 +302,7 @@ class MMTrainerForgetting:
                 if "forget_ce" in lt:
                     forget_loss = forget_outputs.loss
                 elif "forget_entropy" in lt:
-                    forget_loss = tu.entropy_term(forget_outputs.logits)
+                    forget_loss = tu.entropy_term(forget_outputs.logits) / self._merge  # a plain SUM over all rows
                 elif "forget_kl" in lt:
                     oracle = self._teacher(forget_inputs)
                     forget_loss = tu.kl_div_batchmean(forget_outputs.logits, oracle.logits, student_is_input=True)
@@ -318,7 +389,7 @@ class MMTrainerForgetting:
             K = random_inputs["input_ids"].shape[1]
             random_loss = 0.0
             for i in range(K):
-                random_loss = random_loss + self._loss_of(model, {k: v[:, i] for k, v in random_inputs.items()}).loss
+                random_loss = random_loss + self._loss_of(model, {k: _slice_k(v, i) for k, v in random_inputs.items()}).loss
             oracle_r = self._teacher(retain_inputs)
             outputs = model(**retain_inputs)
             normal_loss = -1 * tu.kl_div_batchmean(outputs.logits, oracle_r.logits, student_is_input=True)
@@ -357,32 +428,34 @@ class MMTrainerForgetting:
         l1, l0 = self.l1_lambda, self.l0_lambda
         if not ((l1 is not None and l1 != 0) or (l0 is not None and l0 != 0)):
             return 0.0
-        params = []
         lora = tu.has_lora_adapter(model)
+        if self.l_norm_from == "init" and not lora and self.teacher_model is None:
+            raise ValueError("Teacher model is required for L1\\L0 regularization during training without LORA!")
+        if self.l_norm_from == "zero" and lora:
+            raise ValueError("L1\\L0 regularization is not supported for LORA!")
+        flat = getattr(model, "train_flat", None)
+        against_teacher = self.l_norm_from == "init" and not lora
+        tflat = getattr(self.teacher_model, "train_flat", None) if against_teacher else None
+        if flat is not None and flat.is_cuda and (not against_teacher or (tflat is not None and tflat.shape == flat.shape)):
+            # LlavaHIP keeps every trainable tensor in ONE flat parameter: one streaming HIP pass over it (and over the
+            # teacher's) instead of the reference's `p - tp` temporaries + 13.5 GB torch.cat; the backward adds
+            # lambda1 * sign(d) straight into the flat gradient.  Nothing of parameter size is allocated here.
+            if tflat is not None:
+                tflat = tflat.detach()
+                if tflat.device != flat.device:
+                    tflat = tflat.to(flat.device)
+            return _L1L0Fn.apply(flat, model, tflat, float(l1 or 0.0), float(l0 or 0.0))
+        params = []
         if self.l_norm_from == "init":
             if lora:
                 params = [p.view(-1) for p in model.parameters() if p.requires_grad]
             else:
-                if self.teacher_model is None:
-                    raise ValueError("Teacher model is required for L1\\L0 regularization during training without LORA!")
                 for p, tp in zip(model.parameters(), self.teacher_model.parameters()):
                     assert p.shape == tp.shape
                     if p.requires_grad:
                         params.append((p - tp.to(p.device)).view(-1))
         elif self.l_norm_from == "zero":
-            if lora:
-                raise ValueError("L1\\L0 regularization is not supported for LORA!")
             params = [p.view(-1) for p in model.parameters() if p.requires_grad]
-        flat = getattr(model, "train_flat", None)
-        if flat is not None and flat.is_cuda and len(params) == 1:
-            # LlavaHIP: one streaming HIP pass over the flat trainable buffer (and the teacher's) instead of a
-            # 13.5 GB torch.cat temporary; the backward adds lambda1 * sign(d) straight into the flat gradient
-            tflat = None
-            if self.l_norm_from == "init" and not lora:
-                tflat = next(iter(self.teacher_model.parameters())).detach()
-                if tflat.device != flat.device:
-                    tflat = tflat.to(flat.device)
-            return _L1L0Fn.apply(flat, model, tflat, float(l1 or 0.0), float(l0 or 0.0))
         reg = 0.0
         cat = torch.cat(params).float()
         if l1 is not None and l1 != 0:
@@ -420,7 +493,7 @@ class CustomTrainerForgetting(MMTrainerForgetting):
         out = tuple(t.to(device) for t in inputs[:3])
         for d, v in zip(out[1:], inputs[1:3]):  # labels, attention_mask: the device copies remember the collator's tensors
             if d is not v and v.device.type == "cpu":
-                d._mmu_host = v
+                attach_host(d, v)
         return out
 
     @staticmethod
@@ -428,7 +501,38 @@ class CustomTrainerForgetting(MMTrainerForgetting):
         ids, labels, mask = t
         return {"input_ids": ids, "attention_mask": mask, "labels": labels}
 
+    def can_merge(self, model) -> bool:
+        lt = self.loss_type_raw
+        return hasattr(model, "loss_segments") and (lt in ("retain_ft", "grad_ascent", "scrub", "eco_ft", "dpo", "KL", "LLMU", "npo")
+                                                    or lt.startswith("grad_diff"))
+
+    def merge_micro_batches(self, model, micro_batches, pad_token_id: int = 0):
+        """Tuple form of MMTrainerForgetting.merge_micro_batches: [(ids, labels, mask) x (forget, retain[, idk])] per
+        micro-batch -> one such list over the concatenated batch (equal shapes only: the text collator pads every batch
+        to max_length, nlp/data_module.py:10-43).  `idk` (one mean over cat(forget, retain)) and RMU are not merged."""
+        if len(micro_batches) < 2 or not self.can_merge(model):
+            return None
+        first = micro_batches[0]
+        if any(len(mb) != len(first) for mb in micro_batches):
+            return None
+        out = []
+        for j in range(len(first)):
+            parts = [mb[j][:3] for mb in micro_batches]
+            if any(t.shape != parts[0][i].shape for p in parts for i, t in enumerate(p)):
+                return None
+            out.append(tuple((torch.cat if i == 0 else cat_with_host)([p[i] for p in parts], dim=0) for i in range(3)))
+        return out
+
     def compute_loss(self, model, inputs, return_outputs=False, *args, **kwargs):
+        g = int(kwargs.pop("_merge", 1))
+        if g > 1:
+            if not self.can_merge(model):
+                raise ValueError(f"forget_loss={self.loss_type_raw} cannot evaluate merged micro-batches on this model")
+            self._merge, keep_seg, model.loss_segments = g, model.loss_segments, g
+            try:
+                return self.compute_loss(model, inputs, return_outputs, *args, **kwargs)
+            finally:
+                self._merge, model.loss_segments = 1, keep_seg
         forget_t, retain_t, *idk_t = inputs
         dev = next(model.parameters()).device
         f, r = self._split(self.to_device(dev, forget_t)), self._split(self.to_device(dev, retain_t))
@@ -446,11 +550,8 @@ class CustomTrainerForgetting(MMTrainerForgetting):
             from .llava import row_loss_sum
             loss = 2 / beta * row_loss_sum(outputs.logits, oracle.logits, hip.NPO_NLP, beta) / n
         elif lt == "idk":
-            cat = {k: torch.cat((f[k], r[k]), dim=0) for k in ("input_ids", "attention_mask", "labels")}
-            for k in ("attention_mask", "labels"):
-                hf_, hr_ = getattr(f[k], "_mmu_host", None), getattr(r[k], "_mmu_host", None)
-                if hf_ is not None and hr_ is not None:
-                    cat[k]._mmu_host = torch.cat((hf_, hr_), dim=0)
+            cat = {k: (torch.cat if k == "input_ids" else cat_with_host)((f[k], r[k]), dim=0)
+                   for k in ("input_ids", "attention_mask", "labels")}
             outputs = self._loss_of(model, cat, return_outputs)
             loss = outputs.loss
         elif lt == "RMU":
@@ -494,6 +595,18 @@ def hosted_by_hf_trainer(plugin=MMTrainerForgetting):
 
     class Hosted(plugin, transformers.Trainer):
         def _init_host(self, *args, **kwargs):
+            import os
+
+            m = kwargs.get("model", args[0] if args else None)
+            if int(os.environ.get("WORLD_SIZE", "1")) > 1 and hasattr(m, "train_flat") and not getattr(m, "ddp_compatible", False):
+                # transformers.Trainer would wrap the model in torch DDP (mm/forget.py:161 ddp_find_unused_parameters), whose
+                # reducer listens on the parameter's AccumulateGrad node; LlavaHIP's autograd edge accumulates into the
+                # flat gradient buffer by hand and returns no gradient, so DDP would never see (or reduce) anything and
+                # the replicas would drift apart silently.
+                raise RuntimeError(
+                    "hosted_by_hf_trainer() at WORLD_SIZE > 1: torch DDP cannot see LlavaHIP's hand-written gradient "
+                    "accumulation.  Run data-parallel training through multimodal_unlearning_amd.engine.ForgetEngine "
+                    "(python -m multimodal_unlearning_amd.forget --gpus N ...), which owns the bucketed RCCL exchange.")
             transformers.Trainer.__init__(self, *args, **kwargs)
             # the reference's pinned transformers (4.45.1) divides every micro-batch loss by the accumulation steps;
             # 5.x skips that for models whose forward takes **kwargs unless this is False

@@ -30,6 +30,76 @@ def has_lora_adapter(model) -> bool:  # mm/trainer_utils.py:12-13
     return any(True for name, _ in model.named_parameters() if "lora" in name)
 
 
+class _LogProbs(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits2d, log):
+        M, V = logits2d.shape
+        out = torch.empty(M, V, device=logits2d.device, dtype=torch.float32)
+        lse = torch.empty(M, device=logits2d.device, dtype=torch.float32)
+        hip.logprobs_fwd(logits2d, out, lse, log)
+        ctx.save_for_backward(logits2d, lse)
+        ctx.log = log
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        logits2d, lse = ctx.saved_tensors
+        dl = torch.empty_like(logits2d)
+        hip.logprobs_bwd(logits2d, lse, g.contiguous().float(), dl, ctx.log)
+        return dl, None
+
+
+def logits2probs(logits, log=True):
+    """mm/trainer_utils.py:16-21 by name: (log-)softmax over the vocabulary, flattened to [N, V], fp32 as under the
+    reference's autocast, differentiable — one HIP kernel each way (`mmu_logprobs_fwd/bwd`).  The loss branches of this
+    package never call it (they read the logits once through `mmu_rowloss_*` and materialise nothing, 4 V bytes per row
+    saved each time); it exists so that code written against the reference's helper keeps working."""
+    V = logits.shape[-1]
+    x = logits.reshape(-1, V)
+    if x.is_cuda and x.dtype == torch.bfloat16 and V % 8 == 0:
+        return _LogProbs.apply(x.contiguous(), bool(log))
+    raise TypeError("logits2probs: expected bf16 logits on the GPU with a vocabulary that is a multiple of 8 "
+                    "(the HIP path has no eager substitute)")
+
+
+class DecoderLayerHandle:
+    """What `model.language_model.model.layers[i]` is to the reference's forward_with_cache (mm/trainer.py:302-310): names
+    decoder layer `index` of a LlavaHIP, which has no nn.Module per layer.  `LlavaHIP.decoder_layers[i]` builds one."""
+
+    def __init__(self, index: int):
+        self.index = int(index)
+
+
+def forward_with_cache(model, inputs, module, no_grad=True):
+    """mm/trainer_utils.py:24-45 by name: the output of `module` ([B, S, H]) during `model(**inputs)`.  For a LlavaHIP,
+    `module` is a DecoderLayerHandle (or a plain layer index) and the forward sweep stops at that layer
+    (`LlavaHIP.hidden_states`: the layers above cannot influence the activation or its gradient); for any other
+    nn.Module the reference's forward hook is used as is."""
+    if hasattr(model, "hidden_states") and isinstance(module, (int, DecoderLayerHandle)):
+        layer = module if isinstance(module, int) else module.index
+        kw = {k: v for k, v in inputs.items() if k != "labels"}
+        if no_grad:
+            with torch.no_grad():
+                return model.hidden_states(layer, **kw)
+        return model.hidden_states(layer, **kw)
+    cache = []
+
+    def hook(_m, _inp, output):
+        cache.append(output[0] if isinstance(output, tuple) else output)
+        return None
+
+    handle = module.register_forward_hook(hook)
+    try:
+        if no_grad:
+            with torch.no_grad():
+                model(**inputs)
+        else:
+            model(**inputs)
+    finally:
+        handle.remove()
+    return cache[0]
+
+
 def kl_div_batchmean(input_logits, target_logits, student_is_input: bool):
     """F.kl_div(logits2probs(input), logits2probs(target), reduction="batchmean", log_target=True) as the reference
     calls it (mm/trainer.py:203-208 etc.): divides by ALL B*S rows.  Exactly one side is the student (the side

@@ -151,3 +151,47 @@ def test_forget_entry_point_on_two_ranks(tmp_path, dp_mode):
     assert res[0][0] == res[1][0] == 16 // (2 * 2 * 2)      # max_steps = epochs * len // (batch * GA * world)
     assert torch.equal(res[0][1], res[1][1])
     assert os.path.exists(os.path.join(out, "config.yaml")) and os.path.exists(os.path.join(out, "config.json"))
+
+
+def _merge_worker(rank, world, port, q, model_path, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from multimodal_unlearning_amd.forget import ForgetRunConfig, parse_overrides, run
+
+    if rank == 1:  # the slow rank of ADVICE r3: rank 0 must not rewrite model_path while this one is still reading it
+        import time
+        time.sleep(3.0)
+    rc = parse_overrides(["model_family=tiny", f"save_dir={out_dir}", f"model_path={model_path}", "forget_data_path=synthetic:8",
+                          "batch_size=2", "gradient_accumulation_steps=1", "num_epochs=1", "seq_len=40", "lr=0.0",
+                          "forget_loss=retain_ft", "max_steps=1", "save_model=false"], ForgetRunConfig())
+    eng = run(rc)
+    q.put((rank, eng.model.train_flat.detach().float().cpu().numpy()))
+
+
+def test_forget_entry_point_merges_a_lora_run_on_two_ranks(tmp_path):
+    """mm/forget.py:100-113 at world 2 with model_path = a LoRA run's save_dir: every rank must start from the MERGED weights
+    (rank 0 decides what the directory holds, nobody rewrites it while another rank reads, all ranks take the same
+    barriers), the directory ends as a plain checkpoint with the adapter retired."""
+    from multimodal_unlearning_amd.forget import ForgetRunConfig, parse_overrides, run
+
+    a = str(tmp_path / "a")
+    base = ["model_family=tiny", "forget_data_path=synthetic:8", "batch_size=2", "gradient_accumulation_steps=1", "seq_len=40"]
+    e1 = run(parse_overrides(base + [f"save_dir={a}", "forget_loss=grad_ascent", "LoRA.r=8", "num_epochs=2", "lr=5e-3"], ForgetRunConfig()))
+    e1.model.merge_lora_()
+    merged = e1.model._base_flat.detach().float().cpu()
+    del e1
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_merge_worker, args=(r, 2, port, q, a, str(tmp_path / "b"))) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = {r: torch.from_numpy(x) for r, x in (q.get(timeout=300) for _ in ps)}
+    for p in ps:
+        p.join(120)
+        assert p.exitcode == 0
+    assert torch.equal(res[0], res[1])
+    assert (res[0] - merged).norm() / merged.norm() < 1e-6
+    assert not os.path.exists(os.path.join(a, "adapter_config.json")) and os.path.exists(os.path.join(a, "adapter_config.json.merged"))
+    assert not os.path.exists(os.path.join(a, ".merge_tmp"))

@@ -1,0 +1,215 @@
+"""Gradient-accumulation micro-batches evaluated as ONE concatenated batch (ForgetEngine._groups,
+MMTrainerForgetting.merge_micro_batches) against the micro-batch loop the reference's host loop runs
+(transformers.Trainer.training_step once per micro-batch, loss / GA; mm/forget.py:139-190, config/mm/forget.yaml:14-15).
+
+Rows of a batch never interact and every loss term is a mean over equal-sized sets, a per-segment token mean (segmented CE
+kernel) or a plain sum, so the merged step must reproduce the looped one up to summation order:
+  mean loss          |d| < 1e-6 * max(1, |loss|)     (fp32 reductions of identical bf16 logits)
+  updated parameters relative L2 of the UPDATE < 2e-3 ... measured against the size of the update itself where stated,
+                     and rel-L2 < 2e-3 of the parameters as VERDICT asks
+Also here: the helper shims `logits2probs` / `forward_with_cache` (mm/trainer_utils.py:16-45) and the L1 regulariser's
+memory behaviour (mm/trainer.py:451-481)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from multimodal_unlearning_amd.config import ForgetConfig, tiny_test_config  # noqa: E402
+from multimodal_unlearning_amd.params import init_params  # noqa: E402
+from multimodal_unlearning_amd.synthetic import make_forget_batch, make_split, make_text_split, teacher_params_from  # noqa: E402
+
+SPLITS = ("forget", "retain", "idk")
+
+
+def _engine(dev, loss, merge, text=False, loss_args=None, lr=1e-3):
+    from multimodal_unlearning_amd.engine import ForgetEngine
+    from multimodal_unlearning_amd.llava import LlavaHIP
+    from multimodal_unlearning_amd.trainer import CustomTrainerForgetting, MMTrainerForgetting
+
+    cfg = tiny_test_config()
+    P = init_params(cfg, seed=0)
+    model = LlavaHIP(cfg, P, device=dev)
+    teacher = LlavaHIP(cfg, teacher_params_from(P, seed=7), device=dev, trainable=False)
+    if text:
+        tr = CustomTrainerForgetting(model=model, forget_loss=loss, oracle_model=teacher, loss_beta=1.0, l1_lambda=0.0,
+                                     l0_lambda=0.0, loss_args=loss_args or {})
+    else:
+        tr = MMTrainerForgetting(model=model, forget_loss=loss, teacher_model=teacher, loss_beta=1.0, l1_lambda=0.0,
+                                 l0_lambda=0.0, l_norm_from="zero", loss_args=loss_args or {})
+    eng = ForgetEngine(model, tr, ForgetConfig(lr=lr), total_steps=10, warmup_steps=0, merge_ga=merge)
+    return cfg, model, eng
+
+
+def _run(dev, loss, merge, mbs_of, text=False, loss_args=None, steps=2):
+    cfg, model, eng = _engine(dev, loss, merge, text, loss_args)
+    p0 = model.train_flat.detach().float().clone()
+    losses, groups = [], []
+    for k in range(steps):
+        st = eng.step(mbs_of(cfg, k), sync_loss=True)
+        losses.append(st.loss)
+        groups.append(list(eng.last_groups))
+    torch.cuda.synchronize()
+    return losses, model.train_flat.detach().float().clone(), p0, groups
+
+
+def _mm_batches(ga, B=2, S=40):
+    return lambda cfg, k: [make_forget_batch(cfg, B, S, seed=100 + 10 * k + i, n_question=5 + i, splits=SPLITS) for i in range(ga)]
+
+
+@pytest.mark.parametrize("loss,loss_args", [
+    ("grad_diff_forget_ce_retain_ce", None),                 # paired fusion: 2 * GA segments in one sweep
+    ("grad_diff_forget_ce_retain_ce", {"fuse_pairs": False}),
+    ("grad_diff_forget_ce_retain_ce", {"loss_only_head": False}),
+    ("KL", None),                                            # CE (segmented, loss-only head) + KL batchmean
+    ("npo", None),                                           # mean over B*S*V
+    ("scrub", None),                                         # two KL terms + CE on the full logits (segmented)
+    ("llmu", None),
+    ("dpo", None),                                           # per-sequence CE sums, mean over sequences
+    ("grad_diff_forget_entropy_retain_kl", None),            # a plain SUM term: divided by g
+    ("idk", None),
+    ("grad_ascent", None),
+])
+def test_merged_step_matches_the_micro_batch_loop(dev, loss, loss_args):
+    ga = 3  # not a power of two: the 1/GA weights are not exact binary fractions
+    a = _run(dev, loss, True, _mm_batches(ga), loss_args=loss_args)
+    b = _run(dev, loss, False, _mm_batches(ga), loss_args=loss_args)
+    assert a[3] == [[ga], [ga]] and b[3] == [[1] * ga, [1] * ga], (a[3], b[3])
+    for la, lb in zip(a[0], b[0]):
+        tol = 1e-6 * max(1.0, abs(lb)) if loss != "grad_diff_forget_entropy_retain_kl" else 1e-5 * max(1.0, abs(lb))
+        assert abs(la - lb) <= tol, (loss, la, lb)
+    moved = (b[1] - b[2]).norm()
+    assert moved > 1e-3 * b[2].norm()                                   # the steps did move the parameters
+    err = (a[1] - b[1]).norm()
+    print(f"{loss}: merged vs looped: losses {a[0]} / {b[0]}; |dp| {err / b[1].norm():.2e} of |p|, {err / moved:.2e} of the update")
+    assert err < 2e-3 * b[1].norm()
+    # AdamW's first updates are +-lr per element whatever the gradient's size, so a sign flip of a near-zero bf16 gradient
+    # moves an element by 2 lr: bound the share of the update that differs, not element equality
+    assert err < 0.12 * moved, (float(err), float(moved))
+
+
+def test_merged_groups_follow_the_token_budget(dev):
+    """merge_tokens caps the positions of one forward: GA 4 of 2 pairs x 40 positions x 2 splits (+ idk) with a cap of two
+    micro-batches runs as two merged groups; a cap below two micro-batches is the plain loop."""
+    cfg, model, eng = _engine(dev, "grad_diff_forget_ce_retain_ce", True)
+    mbs = [make_forget_batch(cfg, 2, 40, seed=7 + i, n_question=6) for i in range(4)]
+    per = 2 * 2 * 40
+    for cap, want in ((2 * per, [2, 2]), (3 * per, [3, 1]), (per, [1, 1, 1, 1]), (100 * per, [4])):
+        eng.merge_tokens = cap
+        eng.step(mbs)
+        assert eng.last_groups == want, (cap, eng.last_groups)
+    eng.merge_tokens = "auto"   # plenty of free HBM for the tiny model
+    eng.step(mbs)
+    assert eng.last_groups == [4]
+
+
+def test_merged_ragged_micro_batches_are_left_padded_for_ce_losses(dev):
+    """Micro-batches of different sequence length (the collator pads each batch to ITS longest row, mm/dataset.py:291-354)
+    merge for the CE-only losses by left-padding to the longest; KL-type losses (normalised over all B*S rows) refuse and
+    run the loop."""
+    lens = (40, 33, 48)
+
+    def mbs_of(cfg, k):
+        return [make_forget_batch(cfg, 2, S, seed=300 + 10 * k + i, n_question=5) for i, S in enumerate(lens)]
+
+    a = _run(dev, "grad_diff_forget_ce_retain_ce", True, mbs_of)
+    b = _run(dev, "grad_diff_forget_ce_retain_ce", False, mbs_of)
+    assert a[3] == [[3], [3]]
+    for la, lb in zip(a[0], b[0]):
+        assert abs(la - lb) < 2e-3 * max(1.0, abs(lb)), (la, lb)   # RoPE positions shift by the padding: bf16 table rounding
+    moved = (b[1] - b[2]).norm()
+    assert (a[1] - b[1]).norm() < 0.3 * moved
+    c = _run(dev, "KL", True, mbs_of, steps=1)
+    assert c[3] == [[1, 1, 1]]
+
+
+def test_text_trainer_merges_tuple_micro_batches(dev):
+    def mbs_of(cfg, k):
+        out = []
+        for i in range(2):
+            sp = [make_text_split(cfg, 2, 32, seed=500 + 10 * k + 3 * i + j, n_question=6, right_pad=[0, 5]) for j in range(2)]
+            out.append([(s["input_ids"], s["labels"], s["attention_mask"]) for s in sp])
+        return out
+
+    for loss in ("grad_diff_forget_KL_retain_ce", "npo", "grad_ascent"):
+        a = _run(dev, loss, True, mbs_of, text=True)
+        b = _run(dev, loss, False, mbs_of, text=True)
+        assert a[3] == [[2], [2]] and b[3] == [[1, 1], [1, 1]]
+        for la, lb in zip(a[0], b[0]):
+            assert abs(la - lb) <= 1e-6 * max(1.0, abs(lb)), (loss, la, lb)
+        assert (a[1] - b[1]).norm() < 0.12 * (b[1] - b[2]).norm()
+    c = _run(dev, "idk", True, mbs_of, text=True, steps=1)   # one mean over cat(forget, retain): not a per-segment mean
+    assert c[3] == [[1, 1]]
+
+
+def test_host_views_notice_in_place_edits(dev):
+    """the host shortcut for masks / labels must not survive an in-place edit of either side."""
+    from multimodal_unlearning_amd.llava import attach_host, host_of
+    from multimodal_unlearning_amd.trainer import MMTrainerForgetting
+
+    h = torch.ones(2, 8, dtype=torch.int64)
+    d = MMTrainerForgetting.to_device(dev, {"attention_mask": h, "labels": h.clone()})["attention_mask"]
+    assert host_of(d) is h
+    d[0, 0] = 0                       # a host loop masks a token on the device copy
+    assert host_of(d) is None
+    assert not bool(host_of(d, fetch=True).all())   # re-fetched from the device: sees the edit
+    d2 = h.to(dev)
+    attach_host(d2, h)
+    h[1, 1] = 0                       # ... or reuses the host buffer
+    assert host_of(d2) is None
+
+
+def test_logits2probs_and_forward_with_cache_shims(dev):
+    """mm/trainer_utils.py:16-45 by name: values vs torch on the same bf16 logits, gradients vs autograd of the torch
+    expression; forward_with_cache == LlavaHIP.hidden_states == the capture of a full forward."""
+    from multimodal_unlearning_amd import trainer_utils as tu
+    from multimodal_unlearning_amd.llava import LlavaHIP
+
+    g = torch.Generator(device=dev).manual_seed(0)
+    x = (torch.randn(3, 5, 4096, device=dev, generator=g) * 3).to(torch.bfloat16)
+    for log in (True, False):
+        xs = x.clone().requires_grad_(True)
+        out = tu.logits2probs(xs, log=log)
+        xr = x.float().clone().requires_grad_(True)
+        ref = (torch.log_softmax if log else torch.softmax)(xr, dim=-1).view(-1, 4096)
+        assert out.shape == ref.shape and out.dtype == torch.float32
+        assert (out - ref).abs().max() < (2e-5 if log else 2e-6)
+        w = torch.randn(ref.shape, device=dev, generator=g)
+        (out * w).sum().backward()
+        (ref * w).sum().backward()
+        assert ((xs.grad.float() - xr.grad).norm() / xr.grad.norm()) < 4e-3     # bf16 rounding of the gradient
+    cfg = tiny_test_config()
+    model = LlavaHIP(cfg, init_params(cfg, seed=0), device=dev)
+    sp = make_split(cfg, 2, 40, seed=3, n_question=6)
+    act = tu.forward_with_cache(model, sp, model.decoder_layers[0], no_grad=True)
+    assert not act.requires_grad and act.shape == (2, 40, cfg.text.hidden_size)
+    model.capture_layer = 0
+    full = model(**{k: v for k, v in sp.items() if k != "labels"}).hidden_states
+    model.capture_layer = None
+    assert torch.equal(act, full.detach())
+    act2 = tu.forward_with_cache(model, sp, 0, no_grad=False)
+    assert act2.requires_grad
+
+
+def test_l1_regulariser_allocates_nothing_of_parameter_size(dev):
+    """with l_norm_from="init" the reference forms `p - tp` per parameter and torch.cat's them
+    (mm/trainer.py:451-481); on the flat HIP path neither may appear — peak memory must not grow by the parameter size."""
+    from multimodal_unlearning_amd.llava import LlavaHIP
+    from multimodal_unlearning_amd.trainer import MMTrainerForgetting
+
+    cfg = tiny_test_config(vocab=32768)   # 2 x 32768 x 256 embedding + head: ~35 MB of bf16 parameters, far above allocator rounding
+    P = init_params(cfg, seed=0)
+    model = LlavaHIP(cfg, P, device=dev)
+    teacher = LlavaHIP(cfg, teacher_params_from(P, seed=7), device=dev, trainable=False)
+    nbytes = model.train_flat.numel() * 2
+    for frm in ("init", "zero"):
+        tr = MMTrainerForgetting(model=model, forget_loss="grad_ascent", teacher_model=teacher, loss_beta=1.0,
+                                 l1_lambda=0.25, l0_lambda=0.5, l_norm_from=frm, loss_args={})
+        model.ensure_grad()
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        reg = tr._l_norm_regulariser(model)
+        reg.backward()
+        torch.cuda.synchronize()
+        grew = torch.cuda.max_memory_allocated() - base
+        assert grew < nbytes // 8, (frm, grew, nbytes)
