@@ -97,6 +97,29 @@ class GemmTimer:
                 self.records.append((self.hip.NT, x.shape[0], w.shape[0], x.shape[1], e0, e1, False, False))
             return launched
 
+        def timed_swiglu(which):
+            fn = getattr(self.hip, which)
+
+            def f(*a, **kw):   # the GEMMs with the SwiGLU forward / backward in their epilogue (same 256^2 kernel)
+                s = torch.cuda.current_stream()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(s)
+                launched = fn(*a, **kw)
+                e1.record(s)
+                if launched:
+                    if which == "gemm_swiglu_fwd":   # (x, w_gu, gu, act, act_t)
+                        m, k, n = a[0].shape[0], a[0].shape[1], a[1].shape[0]
+                    else:                            # (dh, w, w_t, gu, dgu, dgu_t)
+                        m, k, n = a[0].shape[0], a[0].shape[1], a[3].shape[1] // 2
+                    self.records.append((self.hip.NT, m, n, k, e0, e1, False, which))
+                return launched
+            return fn, f
+
+        self.orig_sw = {}
+        for which in ("gemm_swiglu_fwd", "gemm_swiglu_bwd"):
+            if hasattr(self.hip, which):
+                self.orig_sw[which], wrapped = timed_swiglu(which)
+                setattr(self.hip, which, wrapped)
         self.hip.gemm = timed
         self.hip.gemm_rope = timed_rope
         return self
@@ -104,6 +127,8 @@ class GemmTimer:
     def __exit__(self, *a):
         self.hip.gemm = self.orig
         self.hip.gemm_rope = self.orig_rope
+        for which, fn in self.orig_sw.items():
+            setattr(self.hip, which, fn)
 
     def summary(self):
         torch.cuda.synchronize()
@@ -114,7 +139,10 @@ class GemmTimer:
             ms = e0.elapsed_time(e1)
             f = 2.0 * m * n * k
             # algorithmic HBM bytes of one launch: read A and B once, write C once (+ read C / residual once)
-            self.alg_bytes += 2.0 * (m * k + n * k + m * n * (1 + int(acc) + int(res)))
+            if isinstance(res, str):  # fused SwiGLU GEMMs: fwd writes gu (2I... n = 2I) + act + act^T; bwd reads gu, writes dgu + dgu^T
+                self.alg_bytes += 2.0 * (m * k + n * k + (m * n * 2 if res == "gemm_swiglu_fwd" else m * n * 6))
+            else:
+                self.alg_bytes += 2.0 * (m * k + n * k + m * n * (1 + int(acc) + int(res)))
             tot_f += f
             tot_t += ms * 1e-3
             key = ("NT", "NN", "TN")[layout]
@@ -125,7 +153,7 @@ class GemmTimer:
         # the step's GEMM shapes, heaviest first: where the kernel's time goes and what each shape reaches
         shp = {}
         for layout, m, n, k, e0, e1, acc, res in self.records:
-            b = shp.setdefault((m, n, k, "accumulate" if acc else ("residual" if res else "store")), [0, 0.0])
+            b = shp.setdefault((m, n, k, res[5:] if isinstance(res, str) else ("accumulate" if acc else ("residual" if res else "store"))), [0, 0.0])
             b[0] += 1
             b[1] += e0.elapsed_time(e1) * 1e-3
         self.by_shape = [{"M": m, "N": n, "K": k, "epilogue": ep, "launches": c, "avg_us": round(t / c * 1e6, 1),
@@ -133,6 +161,111 @@ class GemmTimer:
                          for (m, n, k, ep), (c, t) in sorted(shp.items(), key=lambda kv: -kv[1][1])[:16]]
         return tot_f, tot_t, len(self.records), {k: {"launches": v[0], "tflops": round(v[1] / v[2] / 1e12, 1),
                                                      "avg_us": round(v[2] / v[0] * 1e6, 1)} for k, v in by.items()}
+
+
+PEAK_HBM = 8.0e12   # HBM3E bytes/s per MI355X (MI355X_MICROARCH.md)
+
+
+class KernelTimer:
+    """The non-GEMM kernels of the step, timed IN the step like GemmTimer times the GEMMs: every call of the listed
+    multimodal_unlearning_amd.hip functions is bracketed by HIP events on the launch stream and priced with its
+    algorithmic work (attention: 2 m n k per product, causal at half; HBM-bound kernels: bytes each tensor crosses HBM
+    once).  One C call of the attention backward launches two kernels (dQ, then dK/dV): the library re-records a third
+    event between them (mmu_attn_set_bwd_mid_event), so both get their own duration."""
+
+    def __init__(self, hipmod):
+        self.hip = hipmod
+        self.rec = {}     # name -> [launches, seconds-events [(e0, e1)], work per launch list]
+        self.orig = {}
+        nb = lambda t: t.numel() * t.element_size()
+        self.hbm = {
+            "rmsnorm_fwd": lambda a, k: 2 * nb(a[0]) + 4 * a[0].shape[0],
+            "rmsnorm_bwd": lambda a, k: (3 + (a[4] is not None)) * nb(a[0]),
+            "rmsnorm_apply_t": lambda a, k: 2 * nb(a[0]),
+            "swiglu_fwd": lambda a, k: nb(a[0]) + nb(a[1]),
+            "swiglu_fwd_both": lambda a, k: nb(a[0]) + 2 * nb(a[1]),
+            "swiglu_fwd_t": lambda a, k: nb(a[0]) + nb(a[1]),
+            "swiglu_bwd": lambda a, k: nb(a[0]) + nb(a[1]) + nb(a[2]),
+            "swiglu_bwd_t": lambda a, k: nb(a[0]) + nb(a[1]) + 2 * nb(a[2]),
+            "transpose": lambda a, k: 2 * nb(a[0]),
+            "ce_fwd": lambda a, k: nb(a[0]),
+            "ce_bwd": lambda a, k: 2 * nb(a[0]),
+            "adamw": lambda a, k: 24 * a[0].numel(),
+            "sumsq": lambda a, k: nb(a[0]),
+            "gather_rows": lambda a, k: 2 * nb(a[2]),
+            "scatter_rows": lambda a, k: 2 * nb(a[0]),
+            "embed_fwd": lambda a, k: 2 * nb(a[4]),
+        }
+
+    def _wrap_hbm(self, name, fn, cost):
+        def timed(*a, **k):
+            s = torch.cuda.current_stream()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(s)
+            r = fn(*a, **k)
+            e1.record(s)
+            self.rec.setdefault(name, []).append(("bytes", float(cost(a, k)), e0, e1))
+            return r
+        return timed
+
+    def __enter__(self):
+        hip = self.hip
+        for name, cost in self.hbm.items():
+            if hasattr(hip, name):
+                self.orig[name] = getattr(hip, name)
+                setattr(hip, name, self._wrap_hbm(name, self.orig[name], cost))
+        self.orig["attn_fwd"], self.orig["attn_bwd"] = hip.attn_fwd, hip.attn_bwd
+
+        def fwd(q, k, v, out, lse, kmask, B, S, H, D, scale, causal):
+            s = torch.cuda.current_stream()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(s)
+            r = self.orig["attn_fwd"](q, k, v, out, lse, kmask, B, S, H, D, scale, causal)
+            e1.record(s)
+            fl = 4.0 * B * H * S * S * D * (0.5 if causal else 1.0)
+            self.rec.setdefault(f"attn_fwd_kernel<{D},{'causal' if causal else 'full'}>", []).append(("flops", fl, e0, e1))
+            return r
+
+        def bwd(q, k, v, o, lse, kmask, dout, delta, dq, dk, dv, B, S, H, D, scale, causal, **kw):
+            s = torch.cuda.current_stream()
+            e0, em, e1 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            em.record(s)                     # gives the event its handle; the library records it again between the kernels
+            e0.record(s)
+            hip.attn_set_bwd_mid_event(em)
+            r = self.orig["attn_bwd"](q, k, v, o, lse, kmask, dout, delta, dq, dk, dv, B, S, H, D, scale, causal, **kw)
+            e1.record(s)
+            fwd_fl = 4.0 * B * H * S * S * D * (0.5 if causal else 1.0)
+            tag = f"<{D},{'causal' if causal else 'full'}>"
+            # executed products: dQ kernel S, dP, dQ (3); dK/dV kernel S, dP, dV, dK (4); algorithmic backward = 5 products
+            self.rec.setdefault("attn_bwd_dq_kernel" + tag, []).append(("flops", 1.5 * fwd_fl, e0, em))
+            self.rec.setdefault("attn_bwd_dkdv_kernel" + tag, []).append(("flops", 2.0 * fwd_fl, em, e1))
+            self.rec.setdefault("attention backward (dq + dkdv, 5 algorithmic products)" + tag, []).append(("flops", 2.5 * fwd_fl, e0, e1))
+            return r
+
+        hip.attn_fwd, hip.attn_bwd = fwd, bwd
+        return self
+
+    def __exit__(self, *a):
+        for name, fn in self.orig.items():
+            setattr(self.hip, name, fn)
+
+    def summary(self, top_hbm=6):
+        torch.cuda.synchronize()
+        rows = []
+        for name, recs in self.rec.items():
+            kind = recs[0][0]
+            t = sum(e0.elapsed_time(e1) for _, _, e0, e1 in recs) * 1e-3
+            w = sum(x for _, x, _, _ in recs)
+            if t <= 0:
+                continue
+            peak = PEAK_BF16 if kind == "flops" else PEAK_HBM
+            rows.append({"name": name, "bound": "mfma" if kind == "flops" else "hbm", "launches": len(recs),
+                         "avg_us": round(t / len(recs) * 1e6, 1), ("flops" if kind == "flops" else "bytes") + "_per_launch": round(w / len(recs)),
+                         "achieved": round(w / t / 1e12, 3), "unit": "TFLOP/s" if kind == "flops" else "TB/s",
+                         "frac": round(w / t / peak, 4), "total_ms": round(t * 1e3, 2)})
+        att = [r for r in rows if r["bound"] == "mfma"]
+        hbm = sorted((r for r in rows if r["bound"] == "hbm"), key=lambda r: -r["total_ms"])[:top_hbm]
+        return sorted(att, key=lambda r: r["name"]) + hbm
 
 
 def cpu_baseline(cfg, S, budget_layers=4, clip_layers=4):
@@ -420,10 +553,12 @@ def main():
     eng.time_exchange = world > 1
     t0 = time.perf_counter()
     timer = None
+    ktimer = None
     for k in range(args.steps):
         if k == args.steps - 1 and rank == 0:
             timer = GemmTimer(hip)
-            with timer:
+            ktimer = KernelTimer(hip)
+            with timer, ktimer:
                 eng.step(mbs)
         else:
             eng.step(mbs)
@@ -540,7 +675,10 @@ def main():
                          "kernel": "g256::gemm256_kernel / gemm_bf16_kernel (all layouts)",
                          "launches": n, "avg_launch_us": round(t / n * 1e6, 1),
                          "gemm_share_of_step": round(t / (elapsed / args.steps), 3), "by_layout": by,
-                         "by_shape": timer.by_shape},
+                         "by_shape": timer.by_shape,
+                         # the other kernels of the same (last timed) step, event-timed in place: attention forward / dQ /
+                         # dK-dV against the MFMA peak, the heaviest HBM-bound kernels against 8 TB/s
+                         "kernels": ktimer.summary()},
         }
         if args.hbm_kernels and world == 1:
             torch.cuda.empty_cache()

@@ -41,6 +41,18 @@ int mmu_gemm_uses_256(int M, int N, int K);
 int mmu_gemm_bf16_rope(int layout, const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                        const void* lora_u, const void* lora_b, int lora_k, const int* rope_pos, const void* rope_cos,
                        const void* rope_sin, int rope_cols, void* stream);
+/* LlamaMLP down(act_fn(gate(x)) * up(x)) (modeling_llama.py:174-176) with the elementwise stage inside the GEMMs (256x256
+ * kernel; -2 when the shape would not run on it: the caller then issues mmu_gemm_bf16 + mmu_swiglu_*).
+ * mmu_gemm_swiglu_fwd: gu [M][2I] = x W^T (W = [gate rows | up rows] [2I][K], natural order), act [M][I] = bf16(silu(g)) * u
+ *   and, act_t != NULL, act^T [I][ldt] (M % 8 == 0).  A 256-column tile takes its B rows from BOTH halves of W, so a wave
+ *   holds g and u of the same hidden unit.  Bit-identical to mmu_gemm_bf16 + mmu_swiglu_fwd[_both].
+ * mmu_gemm_swiglu_bwd: dact = dh W_down stays in registers (w_layout 0: w = W_down^T [I][K]; 1: w = W_down [K][I]); with g, u
+ *   from gu the epilogue writes dgu [M][2I] and, dgu_t != NULL, dgu^T [2I][ldt].  Bit-identical to mmu_gemm_bf16 +
+ *   mmu_swiglu_bwd[_t]. */
+int mmu_gemm_swiglu_fwd(const void* x, const void* w_gu, void* gu, void* act, void* act_t, int M, int I, int K, int ldx,
+                        int ldw, int ldgu, int ldact, int ldt, void* stream);
+int mmu_gemm_swiglu_bwd(const void* dh, const void* w, int w_layout, const void* gu, void* dgu, void* dgu_t, int M, int I,
+                        int K, int lddh, int ldw, int ldgu, int lddgu, int ldt, void* stream);
 /* Split-K GEMM for small outputs (skinny LoRA adapter wgrads: [32,in] and [out,32] reduced over all tokens): `splits`
  * blocks per tile each reduce a K range and atomically add their fp32 partial into c32 [M][N] (zero on entry).
  * mmu_fold_f32_into_bf16: dst_bf16 += c32 (* mask); c32 = 0. */
@@ -106,6 +118,9 @@ int mmu_attn_bwd_rope_t(const void* q, const void* k, const void* v, int ld, con
  * 512 registers), persistent, K / V fragments in registers, 4-stage Q/dO ring running across item seams.  Bits 8 and up:
  * workgroups of the four-wave kernel (0 = one per CU, else a multiple of 8).  Process-wide tuning / A-B switch. */
 int mmu_attn_set_dkdv_variant(int variant);
+/* Measurement hook, one-shot: the next mmu_attn_bwd* call records `event` (hipEvent_t, timing enabled) on its stream
+ * between its dQ and its dK/dV kernel, so the two kernels of one call can be timed separately inside a step.  NULL cancels. */
+int mmu_attn_set_bwd_mid_event(void* event);
 
 /* ---- Norms (LlamaRMSNorm / CLIP LayerNorm; SURVEY §8a K2,K7) ---- */
 int mmu_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int M, int d, float eps, void* stream);
@@ -121,6 +136,11 @@ int mmu_layernorm_fwd(const void* x, const void* w, const void* b, void* y, int 
  * through the head_dim-128 backward kernels (zero padding leaves Q K^T and every gradient unchanged). */
 int mmu_layernorm_bwd(const void* dy, const void* x, const void* w, const void* dres, void* dx, int M, int d, float eps,
                       void* stream);
+/* LayerNorm parameter gradients for an UNfrozen CLIP tower (`freeze_vision_module: false`, mm/forget.py:117-118,
+ * config/mm/forget.yaml:57): dgamma[j] (+)= sum_r dy[r][j] * xhat[r][j], dbeta[j] (+)= sum_r dy[r][j].  Workspace: stats
+ * 2 * M floats, part 2 * mmu_colsum_nparts(M) * d floats. */
+int mmu_layernorm_bwd_params(const void* dy, const void* x, float* stats, float* part, void* dgamma, void* dbeta,
+                             int accumulate, int M, int d, float eps, void* stream);
 int mmu_quick_gelu_fwd(const void* x, void* y, long long n, void* stream);
 int mmu_quick_gelu_bwd(const void* x, const void* dy, void* dx, long long n, void* stream);
 int mmu_head_pad(const void* src, int ld_src, int d_src, void* dst, int ld_dst, int d_dst, int M, int H, void* stream);

@@ -883,6 +883,9 @@ int launch_fwd(const AttnArgs& a, hipStream_t s) {
 #define MMU_DKDV_DEFAULT 4
 #endif
 static int g_dkdv_variant = MMU_DKDV_DEFAULT;  // mmu_attn_set_dkdv_variant: 8 = eight-wave kernel, 4 = four-wave persistent kernel
+// measurement hook (bench.py): an event the NEXT backward call records between its dQ and its dK/dV kernel, on the
+// stream they are launched on; one-shot.  Lets the two kernels of one C call be timed separately, in the step.
+static hipEvent_t g_bwd_mid_event = nullptr;
 
 template <int D, bool CAUSAL>
 int launch_bwd(const AttnArgs& a, hipStream_t s) {
@@ -922,6 +925,11 @@ int launch_bwd(const AttnArgs& a, hipStream_t s) {
     };
     hipLaunchKernelGGL((attn_bwd_dq_kernel<D, CAUSAL>), dim3(((a.S + 127) / 128) * a.H * a.B), dim3(256), LDS_DQ, s, k);
     MMU_CHECK_LAUNCH();
+    if (g_bwd_mid_event) {
+        const hipError_t ee = hipEventRecord(g_bwd_mid_event, s);
+        g_bwd_mid_event = nullptr;
+        if (ee != hipSuccess) return (int)ee;
+    }
     bool four_wave = false;
     if constexpr (D == 128) {
         // 4 waves x 512 registers, persistent, K / V in registers, 4-stage Q/dO ring (attention_dkdv4.hip); row strides
@@ -1049,6 +1057,13 @@ extern "C" int mmu_debug_read_attn_stamps(unsigned long long* host_out, int n_bl
 // fragments in registers and a 4-stage Q/dO ring.  Process-wide A/B / tuning switch.
 // Bits 8 and up: workgroups of the persistent four-wave kernel (0 = one per CU, else a multiple of 8; the tests use a
 // small grid so that every workgroup crosses item seams).
+// One-shot: the next mmu_attn_bwd* call records `event` (a hipEvent_t created with timing enabled) on its stream between
+// the dQ and the dK/dV kernel.  nullptr cancels.  Measurement only (bench.py times the two kernels separately in the step).
+extern "C" int mmu_attn_set_bwd_mid_event(void* event) {
+    g_bwd_mid_event = (hipEvent_t)event;
+    return 0;
+}
+
 extern "C" int mmu_attn_set_dkdv_variant(int v) {
     const int kind = v & 255, grid = v >> 8;
     if (v < 0 || (kind != 4 && kind != 8)) return -1;

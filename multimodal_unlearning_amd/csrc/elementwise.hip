@@ -539,6 +539,56 @@ __global__ void add_kernel(const bf16* __restrict__ a, const bf16* __restrict__ 
     }
 }
 
+// LayerNorm parameter gradients (unfrozen CLIP tower, mm/forget.py:117-118 `freeze_vision_module: false`):
+//   dgamma[j] = sum_r dy[r][j] * xhat[r][j],  dbeta[j] = sum_r dy[r][j],  xhat = (x - mean_r) * rstd_r.
+// Stage 1: one wave per row leaves {mean, rstd}; stage 2: one thread per column walks a block of rows (coalesced across the
+// threads of a row) and leaves fp32 partials [2][nparts][d]; colsum_partials_kernel folds them into the bf16 gradients.
+__global__ __launch_bounds__(256) void layernorm_stats_kernel(const bf16* __restrict__ x, float* __restrict__ stats, int M,
+                                                              int d, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nch = d >> 3;
+    const bf16* xr = x + (size_t)row * d;
+    float s = 0.f;
+    for (int ch = lane; ch < nch; ch += 64) {
+        const bf16x8 t = *reinterpret_cast<const bf16x8*>(xr + ch * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += bf2f(t[j]);
+    }
+    const float mean = wave_sum(s) / (float)d;
+    float ss = 0.f;
+    for (int ch = lane; ch < nch; ch += 64) {
+        const bf16x8 t = *reinterpret_cast<const bf16x8*>(xr + ch * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float c = bf2f(t[j]) - mean;
+            ss += c * c;
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(ss) / (float)d + eps);
+    if (lane == 0) {
+        stats[2 * (size_t)row] = mean;
+        stats[2 * (size_t)row + 1] = rstd;
+    }
+}
+
+__global__ void layernorm_dwdb_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x, const float* __restrict__ stats,
+                                      float* __restrict__ part, int M, int d, int rows_per_block, int nparts) {
+    const int r0 = blockIdx.y * rows_per_block;
+    const int r1 = min(M, r0 + rows_per_block);
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= d) return;
+    float sw = 0.f, sb = 0.f;
+    for (int r = r0; r < r1; ++r) {
+        const float g = bf2f(dy[(size_t)r * d + j]);
+        sw += g * (bf2f(x[(size_t)r * d + j]) - stats[2 * (size_t)r]) * stats[2 * (size_t)r + 1];
+        sb += g;
+    }
+    part[(size_t)blockIdx.y * d + j] = sw;
+    part[((size_t)nparts + blockIdx.y) * d + j] = sb;
+}
+
 // column-sum of a bf16 matrix [M][d] into fp32 partials (bias gradients): block handles a row range.
 __global__ void colsum_bf16_kernel(const bf16* __restrict__ x, float* __restrict__ part, int M, int d,
                                    int rows_per_block) {
@@ -883,6 +933,27 @@ extern "C" int mmu_layernorm_bwd(const void* dy, const void* x, const void* w, c
                        (const bf16*)w, (const bf16*)dres, (bf16*)dx, M, d, eps)
     if (d <= 1024) { CALL(2); } else if (d <= 2048) { CALL(4); } else { return -1; }
 #undef CALL
+    MMU_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mmu_colsum_nparts(int M);
+// dgamma / dbeta of a LayerNorm (see layernorm_stats_kernel): stats = 2 * M floats, part = 2 * mmu_colsum_nparts(M) * d floats
+// of workspace; accumulate != 0 adds into the bf16 gradients (gradient accumulation), else overwrites them.
+extern "C" int mmu_layernorm_bwd_params(const void* dy, const void* x, float* stats, float* part, void* dgamma, void* dbeta,
+                                        int accumulate, int M, int d, float eps, void* stream) {
+    if (M <= 0 || d <= 0 || (d & 7) || !stats || !part || !dgamma || !dbeta) return -1;
+    hipStream_t s = (hipStream_t)stream;
+    const int nparts = mmu_colsum_nparts(M);
+    hipLaunchKernelGGL(layernorm_stats_kernel, dim3((M + 3) / 4), dim3(256), 0, s, (const bf16*)x, stats, M, d, eps);
+    MMU_CHECK_LAUNCH();
+    hipLaunchKernelGGL(layernorm_dwdb_kernel, dim3((d + 255) / 256, nparts), dim3(256), 0, s, (const bf16*)dy, (const bf16*)x,
+                       stats, part, M, d, 64, nparts);
+    MMU_CHECK_LAUNCH();
+    hipLaunchKernelGGL(colsum_partials_kernel, dim3((d + 31) / 32), dim3(256), 0, s, part, nparts, d, (bf16*)dgamma, accumulate);
+    MMU_CHECK_LAUNCH();
+    hipLaunchKernelGGL(colsum_partials_kernel, dim3((d + 31) / 32), dim3(256), 0, s, part + (size_t)nparts * d, nparts, d,
+                       (bf16*)dbeta, accumulate);
     MMU_CHECK_LAUNCH();
     return 0;
 }

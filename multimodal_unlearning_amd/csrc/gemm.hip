@@ -79,6 +79,19 @@ struct GemmArgs {
     // of class c handed out so far (virtual tile ids c, c + 8, ...), tq[8] the workgroups that have left; the last one
     // to leave zeroes the slot for the next launch that uses it.  nullptr: static walk vt, vt + grid, ...
     int* tq;
+    // fused SwiGLU epilogues (256^2 kernel only; epi_mode 4 / 5, see mmu_gemm_swiglu_fwd / mmu_gemm_swiglu_bwd):
+    //  4: C = gate|up [M][2 gu_I] in its natural column order — the B rows of a 256-column tile are taken from TWO places,
+    //     gate rows i0 .. i0+127 and up rows gu_I + i0 .. (64 + 64 per 128-column group), so a wave's b = 0 / 1 accumulator
+    //     halves hold g and u of the SAME hidden unit —, C2 = act = bf16(silu(g)) * u [M][gu_I], CT = act^T [gu_I][ldct]
+    //  5: the GEMM's output dact [M][gu_I] is never stored: with g, u read from `gu` the epilogue writes C = dgu [M][2 gu_I]
+    //     and CT = dgu^T [2 gu_I][ldct]
+    int epi_mode, gu_I;
+    bf16* C2;
+    int ldc2;
+    bf16* CT;
+    int ldct;
+    const bf16* gu;
+    int ldgu;
 };
 
 __device__ __forceinline__ int swzT(int k) { return ((k & 3) << 1) | (((k >> 3) & 1) << 3); }
@@ -372,6 +385,8 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
 // =================================================================================================
 namespace g256 {
 
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 constexpr int HB = 16384;  // bytes per half-tile
 constexpr int LDS_BYTES = 8 * HB;
 constexpr int TQ_SLOTS = 64;  // tile-queue slots of 16 ints (64 B) each
@@ -387,8 +402,11 @@ struct StageDesc {
     int kofs[2];         // element offset along K of this lane's chunk (K-contiguous) or k row (K-major)
 };
 
+// gu_I > 0 (B operand of the fused gate|up + SwiGLU forward, K-contiguous weights only): half-tile `sub` = 0 holds GATE rows,
+// `sub` = 1 the matching UP rows: local row r <-> weight row sub * gu_I + base0 / 2 + (r >> 6) * 64 + (r & 63).
 template <bool T, bool IS_A>
-__device__ __forceinline__ StageDesc make_desc(const bf16* G, int ld, int base0, int sub, int dim, int wave, int lane) {
+__device__ __forceinline__ StageDesc make_desc(const bf16* G, int ld, int base0, int sub, int dim, int wave, int lane,
+                                               int gu_I = 0) {
     StageDesc d;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -396,7 +414,8 @@ __device__ __forceinline__ StageDesc make_desc(const bf16* G, int ld, int base0,
         if (!T) {
             const int r = t * 8 + (lane >> 3);
             const int c = (lane & 7) ^ (r & 7);
-            const int g = base0 + (IS_A ? a_map(r) : b_map(r)) + sub * 64;
+            const int g = (!IS_A && gu_I > 0) ? sub * gu_I + (base0 >> 1) + ((r >> 6) << 6) + (r & 63)
+                                              : base0 + (IS_A ? a_map(r) : b_map(r)) + sub * 64;
             d.kofs[i] = c * 8;
             d.src[i] = (g < dim) ? (G + (size_t)g * ld + c * 8) : nullptr;
         } else {
@@ -576,8 +595,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
 #endif
     StageDesc dA0 = make_desc<AT, true>(p.A, p.lda, G256_SRC_M(m0), 0, p.M, wave, lane);
     StageDesc dA1 = make_desc<AT, true>(p.A, p.lda, G256_SRC_M(m0), 1, p.M, wave, lane);
-    StageDesc dB0 = make_desc<BT, false>(p.B, p.ldb, G256_SRC_N(n0), 0, p.N, wave, lane);
-    StageDesc dB1 = make_desc<BT, false>(p.B, p.ldb, G256_SRC_N(n0), 1, p.N, wave, lane);
+    const int gu_rows = (EPI == 4) ? p.gu_I : 0;  // B rows of a tile come from the gate AND the up half of the weight
+    StageDesc dB0 = make_desc<BT, false>(p.B, p.ldb, G256_SRC_N(n0), 0, p.N, wave, lane, gu_rows);
+    StageDesc dB1 = make_desc<BT, false>(p.B, p.ldb, G256_SRC_N(n0), 1, p.N, wave, lane, gu_rows);
 
     f32x4 acc[2][2][2][4];  // [a][b][nt][mt]
     bf16x8 fa[2][4];     // [ks][mt]   current A block
@@ -726,6 +746,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     }
     if (wm == 0) G256_BAR();  // balance the stagger barrier
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the overrun prefetches before the LDS is released
+    // the SwiGLU epilogues stage their transposed outputs in the tile buffers: EVERY wave's LDS-DMA must have landed first
+    const bool lds_epi = (EPI == 4 || EPI == 5) && p.CT != nullptr;
+    if (lds_epi) G256_BAR();
 
     if (p.lora_k && k0 == 0) {  // fused low-rank update: acc += U[M][kl] * BL[N][kl]^T (once per tile)
         for (int ks = 0; ks < p.lora_k / 32; ++ks) {
@@ -773,8 +796,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
         decode_tile(p, vt, m0, n0);
         dA0 = make_desc<AT, true>(p.A, p.lda, G256_SRC_M(m0), 0, p.M, wave, lane);
         dA1 = make_desc<AT, true>(p.A, p.lda, G256_SRC_M(m0), 1, p.M, wave, lane);
-        dB0 = make_desc<BT, false>(p.B, p.ldb, G256_SRC_N(n0), 0, p.N, wave, lane);
-        dB1 = make_desc<BT, false>(p.B, p.ldb, G256_SRC_N(n0), 1, p.N, wave, lane);
+        dB0 = make_desc<BT, false>(p.B, p.ldb, G256_SRC_N(n0), 0, p.N, wave, lane, gu_rows);
+        dB1 = make_desc<BT, false>(p.B, p.ldb, G256_SRC_N(n0), 1, p.N, wave, lane, gu_rows);
     }
 
     // Epilogue.  The MFMA leaves each lane with 4 consecutive columns of one row per (nt) tile: stored as is, a wave
@@ -796,6 +819,115 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
                         const int frag = ((a * 4 + mt) * 2 + b) * 2 + nt;
                         *reinterpret_cast<f32x4*>(ws + ((size_t)(frag * 8 + wave) * 64 + lane) * 4) = acc[a][b][nt][mt];
                     }
+    } else if constexpr (EPI == 4 || EPI == 5) {
+        // ---- fused SwiGLU epilogues (see GemmArgs::epi_mode) ----
+        const int g4 = lane >> 4;
+        const int c8 = (g4 & 1) * 16 + (g4 >> 1) * 8;       // first of the lane's 8 columns inside the wave's 32-column run
+        const int cih = (wn & 1) * 32 + c8;
+        const int I = p.gu_I;
+        // transposed outputs: a wave's [128 rows][32 columns] bf16 tile is written column-major into 8448 B of LDS (column
+        // stride 264 B: the four 16-lane groups of a ds_write_b16 land 16 banks apart), read back as 16-B row pieces of
+        // the TRANSPOSED matrix (two ds_read_b64) and stored as 4 x 256-B runs per instruction.
+        MMU_LDS char* xw = (MMU_LDS char*)smem + wave * 8448;
+        const int m_w = cm0 + wm * 128;                      // first row of the wave's tile
+        auto stage_col8 = [&](int a, int mt, const bf16x8& v) {
+            const int r = a * 64 + mt * 16 + (lane & 15);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) *(MMU_LDS bf16*)(xw + (c8 + j) * 264 + r * 2) = v[j];
+        };
+        // t0 -> (first column of the wave's run, row m_w) of the transposed output; ncol: columns of the run that exist
+        auto flush_t = [&](bf16* t0, int ncol) {
+            const int ck = (lane & 15) * 8;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int col = it * 4 + g4;
+                const u32x2_t lo = *(const MMU_LDS u32x2_t*)(xw + col * 264 + ck * 2);
+                const u32x2_t hi = *(const MMU_LDS u32x2_t*)(xw + col * 264 + ck * 2 + 8);
+                if (m_w + ck + 8 <= p.M && col < ncol) {
+                    u32x4_t o = {lo[0], lo[1], hi[0], hi[1]};
+                    *reinterpret_cast<u32x4_t*>(t0 + (size_t)col * p.ldct + ck) = o;
+                }
+            }
+        };
+        if constexpr (EPI == 4) {
+            const int gi = (cn0 >> 1) + (wn >> 1) * 64 + cih;  // hidden unit = act column = gate column; up column gi + I
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const int m = cm0 + wm * 128 + a * 64 + mt * 16 + (lane & 15);
+                    bf16x8 g8, u8, a8;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const auto r0 = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[a][0][0][mt][j]),
+                                                                         __float_as_uint(acc[a][0][1][mt][j]), false, false);
+                        const auto r1 = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[a][1][0][mt][j]),
+                                                                         __float_as_uint(acc[a][1][1][mt][j]), false, false);
+                        g8[j] = f2bf(__uint_as_float(r0[0])); g8[4 + j] = f2bf(__uint_as_float(r0[1]));
+                        u8[j] = f2bf(__uint_as_float(r1[0])); u8[4 + j] = f2bf(__uint_as_float(r1[1]));
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {  // the arithmetic of swiglu_fwd_kernel on the bf16-rounded g, u
+                        const float gf = bf2f(g8[j]);
+                        a8[j] = f2bf(round_bf16(gf / (1.0f + __expf(-gf))) * bf2f(u8[j]));
+                    }
+                    if (m < p.M && gi < I) {
+                        *reinterpret_cast<bf16x8*>(p.C + (size_t)m * p.ldc + gi) = g8;
+                        *reinterpret_cast<bf16x8*>(p.C + (size_t)m * p.ldc + I + gi) = u8;
+                        *reinterpret_cast<bf16x8*>(p.C2 + (size_t)m * p.ldc2 + gi) = a8;
+                    }
+                    if (lds_epi) stage_col8(a, mt, a8);
+                }
+            if (lds_epi) flush_t(p.CT + (size_t)(gi - c8) * p.ldct + m_w, I - (gi - c8));
+        } else {
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int ib = cn0 + (wn >> 1) * 128 + b * 64 + cih;  // hidden unit (column of the never-stored dact)
+                bf16x8 du_keep[2][4];
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) {
+                        const int m = cm0 + wm * 128 + a * 64 + mt * 16 + (lane & 15);
+                        float d8[8];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[a][b][0][mt][j]),
+                                                                            __float_as_uint(acc[a][b][1][mt][j]), false, false);
+                            d8[j] = round_bf16(__uint_as_float(r[0]));       // dact as the stored bf16 tensor would hold it
+                            d8[4 + j] = round_bf16(__uint_as_float(r[1]));
+                        }
+                        bf16x8 dg8, du8;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) { dg8[j] = f2bf(0.f); du8[j] = f2bf(0.f); }
+                        const bool ok = m < p.M && ib < I;
+                        if (ok) {
+                            const bf16x8 g8 = *reinterpret_cast<const bf16x8*>(p.gu + (size_t)m * p.ldgu + ib);
+                            const bf16x8 u8 = *reinterpret_cast<const bf16x8*>(p.gu + (size_t)m * p.ldgu + I + ib);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {  // the arithmetic of swiglu_bwd_kernel
+                                const float gf = bf2f(g8[j]), uf = bf2f(u8[j]), df = d8[j];
+                                const float sig = 1.0f / (1.0f + __expf(-gf));
+                                du8[j] = f2bf(df * round_bf16(gf * sig));
+                                dg8[j] = f2bf(df * uf * (sig * (1.0f + gf * (1.0f - sig))));
+                            }
+                            *reinterpret_cast<bf16x8*>(p.C + (size_t)m * p.ldc + ib) = dg8;
+                            *reinterpret_cast<bf16x8*>(p.C + (size_t)m * p.ldc + I + ib) = du8;
+                        }
+                        if (lds_epi) stage_col8(a, mt, dg8);
+                        du_keep[a][mt] = du8;
+                    }
+                if (lds_epi) {
+                    flush_t(p.CT + (size_t)(ib - c8) * p.ldct + m_w, I - (ib - c8));
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt) stage_col8(a, mt, du_keep[a][mt]);
+                    flush_t(p.CT + (size_t)(I + ib - c8) * p.ldct + m_w, I - (ib - c8));
+                }
+            }
+        }
+        if (lds_epi && more) G256_BAR();  // the next tile's prologue DMA of OTHER waves lands in this wave's staging area
     } else {
     const int g4 = lane >> 4;
     const int cih = (wn & 1) * 32 + (g4 & 1) * 16 + (g4 >> 1) * 8;  // column inside the 128-wide group (< 64)
@@ -907,7 +1039,7 @@ int launch_epi(GemmArgs a, hipStream_t stream) {
     if (split > 8) split = 8;  // (16 ranges of 4 K-tiles measured 1.5 % slower at the reference's micro-batch)
     if (split > nk) split = nk;
     bool sk = g_tail_split && split >= 2 && !(g_tail_split == 3 && (EPI == 1 || a.rope_pos)) && g_sk_ws &&
-              g_sk_ws_bytes >= (size_t)256 * 65536 * sizeof(float);
+              g_sk_ws_bytes >= (size_t)256 * 65536 * sizeof(float) && EPI < 4;  // (the fold kernel has no SwiGLU epilogue)
     if (sk && g_tail_split != 2) {
         const double saving_us = (1.0 - 1.0 / split) * nk * 1.45;  // measured us per K-tile of one tile
         const double cost_us = 15.0 + 0.1 * rem * split;           // partial write + fold read at ~5 TB/s
@@ -936,6 +1068,13 @@ int launch_epi(GemmArgs a, hipStream_t stream) {
 
 template <bool AT, bool BT>
 int launch(const GemmArgs& a, hipStream_t stream) {
+    if constexpr (!AT) {
+        if constexpr (!BT) {
+            if (a.epi_mode == 4) return launch_epi<false, false, 4>(a, stream);
+        }
+        if (a.epi_mode == 5) return launch_epi<false, BT, 5>(a, stream);
+    }
+    if (a.epi_mode) return -1;
     if (a.accumulate) return launch_epi<AT, BT, 2>(a, stream);
     if (a.bias || a.resid || a.act) return launch_epi<AT, BT, 1>(a, stream);
     return launch_epi<AT, BT, 0>(a, stream);
@@ -1150,3 +1289,42 @@ extern "C" int mmu_debug_read_clock_stamps(unsigned long long* host_out, int n_p
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g256::g_clock_stamps), (size_t)n_pairs * 16, 0, hipMemcpyDeviceToHost);
 }
 #endif
+
+// ---- fused SwiGLU GEMMs (256^2 kernel; return -2 when the shape would not run on it: the caller then issues the plain GEMM
+// and the elementwise kernel).  LlamaMLP: down(act_fn(gate(x)) * up(x)), modeling_llama.py:174-176. ----
+//
+// gate|up projection + SwiGLU in one launch: gu [M][2 I] = x W^T (W = [gate rows | up rows] [2 I][K], natural order, as
+// every other consumer of gu expects it), act [M][I] = bf16(silu(g)) * u, and — act_t != NULL — act^T [I][ldt] (the
+// down-projection's weight-gradient operand; needs M % 8 == 0).  Replaces mmu_gemm_bf16 + mmu_swiglu_fwd[_both] with
+// bit-identical outputs (the epilogue rounds g, u to bf16 before the activation exactly as the two-kernel path reads them).
+extern "C" int mmu_gemm_swiglu_fwd(const void* x, const void* w_gu, void* gu, void* act, void* act_t, int M, int I, int K,
+                                   int ldx, int ldw, int ldgu, int ldact, int ldt, void* stream) {
+    if (M <= 0 || I <= 0 || K <= 0 || !x || !w_gu || !gu || !act) return -1;
+    if ((I & 127) || (K & 7) || (ldx & 7) || (ldw & 7) || (ldgu & 7) || (ldact & 7)) return -1;
+    if (((uintptr_t)x | (uintptr_t)w_gu | (uintptr_t)gu | (uintptr_t)act | (uintptr_t)act_t) & 15) return -1;
+    if (act_t && ((M & 7) || (ldt & 7) || ldt < M)) return -1;
+    if (!pick_256(M, 2 * I, K)) return -2;
+    GemmArgs a = {};
+    a.A = (const bf16*)x; a.B = (const bf16*)w_gu; a.C = (bf16*)gu;
+    a.M = M; a.N = 2 * I; a.K = K; a.lda = ldx; a.ldb = ldw; a.ldc = ldgu;
+    a.epi_mode = 4; a.gu_I = I; a.C2 = (bf16*)act; a.ldc2 = ldact; a.CT = (bf16*)act_t; a.ldct = ldt;
+    return g256::launch<false, false>(a, (hipStream_t)stream);
+}
+
+// down-projection dgrad + SwiGLU backward in one launch: dact = dh W_down (w_layout 0: w = W_down^T [I][K = d], the resident
+// transposed copy; 1: w = W_down [K = d][I]) stays in registers; with g, u from gu [M][2 I] the epilogue writes dgu [M][2 I]
+// and — dgu_t != NULL — dgu^T [2 I][ldt] (the gate|up weight-gradient operand; M % 8 == 0).  Replaces mmu_gemm_bf16 +
+// mmu_swiglu_bwd[_t] with bit-identical outputs (dact is rounded to bf16 before use, as the stored tensor was).
+extern "C" int mmu_gemm_swiglu_bwd(const void* dh, const void* w, int w_layout, const void* gu, void* dgu, void* dgu_t, int M,
+                                   int I, int K, int lddh, int ldw, int ldgu, int lddgu, int ldt, void* stream) {
+    if (M <= 0 || I <= 0 || K <= 0 || !dh || !w || !gu || !dgu || (w_layout != 0 && w_layout != 1)) return -1;
+    if ((I & 7) || (K & 7) || (lddh & 7) || (ldw & 7) || (ldgu & 7) || (lddgu & 7)) return -1;
+    if (((uintptr_t)dh | (uintptr_t)w | (uintptr_t)gu | (uintptr_t)dgu | (uintptr_t)dgu_t) & 15) return -1;
+    if (dgu_t && ((M & 7) || (ldt & 7) || ldt < M)) return -1;
+    if (!pick_256(M, I, K)) return -2;
+    GemmArgs a = {};
+    a.A = (const bf16*)dh; a.B = (const bf16*)w; a.C = (bf16*)dgu;
+    a.M = M; a.N = I; a.K = K; a.lda = lddh; a.ldb = ldw; a.ldc = lddgu;
+    a.epi_mode = 5; a.gu_I = I; a.CT = (bf16*)dgu_t; a.ldct = ldt; a.gu = (const bf16*)gu; a.ldgu = ldgu;
+    return w_layout == 0 ? g256::launch<false, false>(a, (hipStream_t)stream) : g256::launch<false, true>(a, (hipStream_t)stream);
+}

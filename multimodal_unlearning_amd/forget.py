@@ -322,7 +322,13 @@ def run(rc: ForgetRunConfig):
         del tmp
         if world > 1:
             dist.barrier()  # the directory is whole again before anyone goes on (all ranks took this branch: has_adapter is rank 0's)
-    model = LlavaHIP(cfg, params, device=dev, lora=lora, seed=rc.seed, init="device" if params is None else "numpy")
+    # mm/forget.py:117-118: `freeze_vision_module` "true" freezes the CLIP tower (the default, config/mm/forget.yaml:57); false
+    # trains it with everything else in full fine-tuning (under LoRA peft freezes every base weight whatever the flag says)
+    model = LlavaHIP(cfg, params, device=dev, lora=lora, seed=rc.seed, init="device" if params is None else "numpy",
+                     freeze_vision=bool(rc.freeze_vision_module) or text)
+    if not rc.freeze_vision_module and not text:
+        log("vision tower: " + ("TRAINABLE (freeze_vision_module=false)" if model.train_vision else
+                                "base weights frozen by LoRA; its adapters train"))
     teacher = None
     if need_teacher:  # the reference loads the same checkpoint a second time (mm/forget.py:91-99)
         teacher = LlavaHIP(cfg, params, device=dev, trainable=False, seed=rc.seed, init="device" if params is None else "numpy")

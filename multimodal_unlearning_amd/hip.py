@@ -23,6 +23,8 @@ SIGNATURES = {
     "mmu_gemm_bf16": [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "mmu_gemm_bf16_lora": [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp],
     "mmu_gemm_uses_256": [_i, _i, _i],
+    "mmu_gemm_swiglu_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "mmu_gemm_swiglu_bwd": [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "mmu_gemm_bf16_rope": [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp],
     "mmu_gemm_bf16_splitk": [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "mmu_fold_f32_into_bf16": [_vp, _vp, _vp, _ll, _vp],
@@ -41,11 +43,13 @@ SIGNATURES = {
     "mmu_attn_bwd_rope_t": [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i,
                             _vp, _vp, _vp, _vp, _i, _vp],
     "mmu_attn_set_dkdv_variant": [_i],
+    "mmu_attn_set_bwd_mid_event": [_vp],
     "mmu_rmsnorm_fwd": [_vp, _vp, _vp, _vp, _i, _i, _f, _vp],
     "mmu_rmsnorm_bwd_nparts": [_i],
     "mmu_rmsnorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "mmu_layernorm_fwd": [_vp, _vp, _vp, _vp, _i, _i, _f, _vp],
     "mmu_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
+    "mmu_layernorm_bwd_params": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
     "mmu_quick_gelu_fwd": [_vp, _vp, _ll, _vp],
     "mmu_quick_gelu_bwd": [_vp, _vp, _vp, _ll, _vp],
     "mmu_head_pad": [_vp, _i, _i, _vp, _i, _i, _i, _i, _vp],
@@ -199,6 +203,39 @@ def gemm_rope(x, w, out, pos_ids, cos_t, sin_t, rope_cols, lora_u=None, lora_b=N
     return True
 
 
+def gemm_swiglu_fwd(x, w_gu, gu, act, act_t=None) -> bool:
+    """gu = x w_gu^T, act = bf16(silu(g)) * u (and act^T) in ONE launch of the 256^2 GEMM (fused epilogue).  Returns False
+    (nothing launched) when the shape would run on the 128^2 kernel: the caller then does gemm + swiglu_fwd."""
+    _bf16c(x, w_gu, gu, act, act_t)
+    M, K = x.shape
+    I = act.shape[1]
+    assert w_gu.shape == (2 * I, K) and gu.shape == (M, 2 * I) and act.shape[0] == M
+    assert act_t is None or (act_t.shape == (I, M) and act_t.stride(1) == 1)
+    rc = load().mmu_gemm_swiglu_fwd(_p(x), _p(w_gu), _p(gu), _p(act), _p(act_t), M, I, K, x.stride(0), w_gu.stride(0),
+                                    gu.stride(0), act.stride(0), 0 if act_t is None else act_t.stride(0), _stream())
+    if rc == -2:
+        return False
+    _check(rc, "mmu_gemm_swiglu_fwd")
+    return True
+
+
+def gemm_swiglu_bwd(dh, w, w_is_transposed_copy, gu, dgu, dgu_t=None) -> bool:
+    """dgu (and dgu^T) = SwiGLU backward of dact = dh W_down, dact never stored.  w: W_down^T [I, d] (resident transposed
+    copy, w_is_transposed_copy=True) or W_down [d, I].  False = shape not on the 256^2 kernel, nothing launched."""
+    _bf16c(dh, w, gu, dgu, dgu_t)
+    M, K = dh.shape
+    I = gu.shape[1] // 2
+    assert w.shape == ((I, K) if w_is_transposed_copy else (K, I)) and dgu.shape == (M, 2 * I)
+    assert dgu_t is None or (dgu_t.shape == (2 * I, M) and dgu_t.stride(1) == 1)
+    rc = load().mmu_gemm_swiglu_bwd(_p(dh), _p(w), 0 if w_is_transposed_copy else 1, _p(gu), _p(dgu), _p(dgu_t), M, I, K,
+                                    dh.stride(0), w.stride(0), gu.stride(0), dgu.stride(0),
+                                    0 if dgu_t is None else dgu_t.stride(0), _stream())
+    if rc == -2:
+        return False
+    _check(rc, "mmu_gemm_swiglu_bwd")
+    return True
+
+
 def gemm_splitk_accumulate(layout, A, B, c32, dst, mask=None, splits=16):
     """dst (bf16 [M,N]) += Aop @ Bop^T (* mask) through a split-K GEMM into the zeroed fp32 scratch c32 [M,N]."""
     _bf16c(A, B, dst, mask)
@@ -296,6 +333,12 @@ def attn_set_dkdv_variant(v: int, grid: int = 0):
     """8 = eight-wave dK/dV kernel; 4 = four-wave persistent register-resident kernel (head_dim 128) on `grid`
     workgroups (0 = one per CU, else a multiple of 8)."""
     _check(load().mmu_attn_set_dkdv_variant(int(v) | (int(grid) << 8)), "mmu_attn_set_dkdv_variant")
+
+
+def attn_set_bwd_mid_event(event):
+    """One-shot measurement hook: `event` (a torch.cuda.Event with timing, already recorded once so its handle exists) is
+    re-recorded by the next attn_bwd between its dQ and its dK/dV kernel."""
+    _check(load().mmu_attn_set_bwd_mid_event(0 if event is None else int(event.cuda_event)), "mmu_attn_set_bwd_mid_event")
 
 
 # ------------------------------------------------------------------------------------------------ norms
@@ -396,6 +439,17 @@ def layernorm_bwd(dy, x, w, dres, dx, eps):
     M, d = x.shape
     _check(load().mmu_layernorm_bwd(_p(dy), _p(x), _p(w), _p(dres), _p(dx), M, d, float(eps), _stream()), "mmu_layernorm_bwd")
     return dx
+
+
+def layernorm_bwd_params(dy, x, dgamma, dbeta, eps, accumulate=True):
+    """dgamma (+)= sum_r dy * xhat, dbeta (+)= sum_r dy of a LayerNorm over rows [M, d] (unfrozen CLIP tower)."""
+    _bf16c(dy, x, dgamma, dbeta)
+    M, d = x.shape
+    assert dy.shape == x.shape and dy.is_contiguous() and x.is_contiguous() and dgamma.numel() == d and dbeta.numel() == d
+    stats = torch.empty(2 * M, device=x.device, dtype=torch.float32)
+    part = torch.empty(2 * colsum_nparts(M) * d, device=x.device, dtype=torch.float32)
+    _check(load().mmu_layernorm_bwd_params(_p(dy), _p(x), _p(stats), _p(part), _p(dgamma), _p(dbeta), int(accumulate), M, d,
+                                           float(eps), _stream()), "mmu_layernorm_bwd_params")
 
 
 def quick_gelu_fwd(x, y):

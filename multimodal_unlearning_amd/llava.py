@@ -237,9 +237,11 @@ class LlavaHIP(nn.Module):
                  seed: int = 0, freeze_vision: bool = True, trainable: bool = True, init: str = "numpy",
                  lora: Optional[LoraSpec] = None):
         super().__init__()
-        if not freeze_vision:
-            raise NotImplementedError("the vision tower is frozen in the forget step (mm/forget.py:117-118)")
         hip.load()  # fail loudly if the HIP library is missing
+        # `freeze_vision_module: false` (config/mm/forget.yaml:57, mm/forget.py:117-118): in full fine-tuning the CLIP tower's
+        # weights, LayerNorms, class / position embeddings and the patch conv train too (their tensors then live in the
+        # trainable flat buffer, in front of the projector).  Under LoRA peft freezes every base weight whatever the flag says.
+        self.train_vision = (not freeze_vision) and lora is None
         self.cfg = cfg
         self.config = cfg  # HF-style alias (reference reads model.config.image_token_index)
         dev = torch.device(device)
@@ -250,7 +252,7 @@ class LlavaHIP(nn.Module):
         nv = nt = 0
         for name, shape in specs.items():
             n = _align8(math.prod(shape))
-            if is_vision(name):
+            if is_vision(name) and not self.train_vision:
                 self._off[name] = ("v", nv, shape)
                 nv += n
             else:
@@ -281,6 +283,7 @@ class LlavaHIP(nn.Module):
         self.transposed_wgrad_min_m = 1024
         self.fuse_rope = os.environ.get("MMU_NO_ROPE_FUSION", "0") != "1"  # A/B switch
         self.fuse_dqkv_t = os.environ.get("MMU_NO_DQKV_T", "0") != "1"     # A/B switch: dqkv^T written by attention backward
+        self.fuse_swiglu = os.environ.get("MMU_NO_SWIGLU_FUSION", "0") != "1"  # A/B switch: SwiGLU fwd / bwd in the GEMM epilogues
         # keep act^T of every layer from forward to backward (+ layers*M*I*2 B, 23 GB at 7B / 30 sequences) instead of
         # recomputing it from gate|up in backward; the owner of the step turns it on when HBM allows (bench.py does)
         self.keep_act_t = False
@@ -589,7 +592,7 @@ class LlavaHIP(nn.Module):
     # -------------------------------------------------------------------------- transposed weight copies
     def _dgrad_weight_names(self):
         names = []
-        if "vision.layers.0.qkv.weight" in self.lora:  # adapted CLIP tower: its backward sweep needs dX = dY W too
+        if "vision.layers.0.qkv.weight" in self.lora or self.train_vision:  # adapted / unfrozen CLIP tower: its backward sweep needs dX = dY W too
             for i in range(self.cfg.vision_layers_used):
                 p = f"vision.layers.{i}."
                 names += [p + "qkv.weight", p + "out.weight", p + "fc1.weight", p + "fc2.weight"]
@@ -786,7 +789,8 @@ class LlavaHIP(nn.Module):
     # CLIP tower + projector -> image features [n_img*np, dt]; returns tensors needed by projector backward
     def _vision_forward(self, pix, save: bool = False):
         cfg, v, w = self.cfg, self.cfg.vision, self.w
-        vlora = "vision.layers.0.qkv.weight" in self.lora
+        # the sweep that keeps what a backward through the tower needs: adapted (LoRA) tower, or unfrozen tower
+        vlora = "vision.layers.0.qkv.weight" in self.lora or self.train_vision
         dev = self.device
         n = pix.shape[0]
         npatch, T, dv = v.num_patches, v.num_patches + 1, v.hidden_size
@@ -849,42 +853,77 @@ class LlavaHIP(nn.Module):
         hip.gelu_fwd(p1, p1a)
         img = torch.empty_like(p1)
         self._lin_fwd("projector.linear_2.weight", p1a, img, bias=w["projector.linear_2.bias"])
-        return img, (feats, p1, p1a, clip_saved, n)
+        # unfrozen tower: the patch conv's im2col operand and the pre-LayerNorm input are kept for their gradients
+        extra = (col, emb) if (self.train_vision and save) else None
+        return img, (feats, p1, p1a, clip_saved, n, extra)
 
-    def _vision_backward(self, clip_saved, dfeats, n):
-        """Reverse sweep through the adapted CLIP layers: only the LoRA adapters of the tower receive gradients (its
-        base weights, LayerNorms and embeddings are frozen), so the chain carries dX only and stops at layer 0.
-        Attention (16 heads x 64, non-causal) runs on the head_dim-64 instantiation of the backward kernels."""
-        v, w = self.cfg.vision, self.w
+    def _vision_backward(self, clip_saved, dfeats, n, extra=None):
+        """Reverse sweep through the CLIP layers.  Adapted tower (LoRA): only the adapters receive gradients (base weights,
+        LayerNorms and embeddings are frozen), so the chain carries dX only and stops at layer 0.  UNfrozen tower
+        (`freeze_vision_module: false`, full fine-tuning): every Linear also gets its weight gradient (the wgrad GEMMs of
+        `_lin_bwd`) and its bias gradient (column sums), every LayerNorm its dgamma / dbeta (`mmu_layernorm_bwd_params`),
+        and the chain continues through the pre-LayerNorm into the position / class embeddings (sums over the images)
+        and the patch conv (dW = d_patch^T im2col).  Attention (16 heads x 64, non-causal) runs on the head_dim-64
+        instantiation of the backward kernels."""
+        v, w, g = self.cfg.vision, self.w, self.g
         dev = self.device
         T, dv, H, D = v.num_patches + 1, v.hidden_size, v.num_heads, v.head_dim
         M = n * T
+        tv = self.train_vision
         dh = torch.zeros(M, dv, device=dev, dtype=BF)
         dh.view(n, T, dv)[:, 1:].copy_(dfeats.view(n, T - 1, dv))  # the CLS row feeds nothing downstream
         scale = D ** -0.5
         delta = torch.empty(2, n, H, T, device=dev, dtype=torch.float32)
+        cpart = torch.empty(hip.colsum_nparts(M) * max(3 * dv, v.intermediate_size), device=dev, dtype=torch.float32) if tv else None
+        eps = v.layer_norm_eps
         for i in reversed(range(len(clip_saved))):
             p = f"vision.layers.{i}."
             h, y1, qkv, a, lse, h2, y2, z, za = clip_saved[i]
             clip_saved[i] = None
             dza = torch.empty_like(za)
             self._lin_bwd(p + "fc2.weight", dh, za, dza)
+            if tv:
+                hip.colsum(dh, cpart, g[p + "fc2.bias"], True)
             dz = torch.empty_like(z)
             hip.quick_gelu_bwd(z, dza, dz)
             dy2 = torch.empty_like(h)
             self._lin_bwd(p + "fc1.weight", dz, y2, dy2)
+            if tv:
+                hip.colsum(dz, cpart, g[p + "fc1.bias"], True)
+                hip.layernorm_bwd_params(dy2, h2, g[p + "ln2.weight"], g[p + "ln2.bias"], eps)
             dh2 = torch.empty_like(h)
-            hip.layernorm_bwd(dy2, h2, w[p + "ln2.weight"], dh, dh2, v.layer_norm_eps)
+            hip.layernorm_bwd(dy2, h2, w[p + "ln2.weight"], dh, dh2, eps)
             da = torch.empty_like(h)
             self._lin_bwd(p + "out.weight", dh2, a, da)
+            if tv:
+                hip.colsum(dh2, cpart, g[p + "out.bias"], True)
             dqkv = torch.empty(M, 3 * dv, device=dev, dtype=BF)
             hip.attn_bwd(qkv[:, :dv], qkv[:, dv:2 * dv], qkv[:, 2 * dv:], a, lse, None, da, delta, dqkv[:, :dv],
                          dqkv[:, dv:2 * dv], dqkv[:, 2 * dv:], n, T, H, D, scale, False)  # native head_dim-64 kernels
             dy1 = torch.empty_like(h)
             self._lin_bwd(p + "qkv.weight", dqkv, y1, dy1)
+            if tv:
+                hip.colsum(dqkv, cpart, g[p + "qkv.bias"], True)
+                hip.layernorm_bwd_params(dy1, h, g[p + "ln1.weight"], g[p + "ln1.bias"], eps)
             dhn = torch.empty_like(h)
-            hip.layernorm_bwd(dy1, h, w[p + "ln1.weight"], dh2, dhn, v.layer_norm_eps)
+            hip.layernorm_bwd(dy1, h, w[p + "ln1.weight"], dh2, dhn, eps)
             dh = dhn
+        if not tv:
+            return
+        # below layer 0: pre-LayerNorm, then emb[b, 0] = class + pos[0], emb[b, 1 + p] = patch[b, p] + pos[1 + p]
+        col, emb = extra
+        hip.layernorm_bwd_params(dh, emb, g["vision.pre_ln.weight"], g["vision.pre_ln.bias"], eps)
+        demb = torch.empty_like(emb)
+        hip.layernorm_bwd(dh, emb, w["vision.pre_ln.weight"], None, demb, eps)
+        # position embedding: the sum over the images of every token row ([n, T * dv] column sums); class embedding: the
+        # same sum restricted to token 0 (it only ever meets pos[0])
+        ppart = torch.empty(hip.colsum_nparts(n) * T * dv, device=dev, dtype=torch.float32)
+        hip.colsum(demb.view(n, T * dv), ppart, g["vision.position_embedding"].view(-1), True)
+        hip.colsum(demb.view(n, T, dv)[:, 0].contiguous(), ppart, g["vision.class_embedding"], True)
+        # patch conv (no bias): dW [dv, C P P (padded)] += d_patch^T im2col; the zero-padded tail columns of the im2col operand
+        # keep the padded weight columns at zero gradient
+        dpatch = demb.view(n, T, dv)[:, 1:].reshape(n * (T - 1), dv)
+        self._wgrad(dpatch, col, "vision.patch_embed.weight")
 
     @property
     def decoder_layers(self):
@@ -952,14 +991,19 @@ class LlavaHIP(nn.Module):
             rstd2 = torch.empty(M, device=dev, dtype=torch.float32)
             hip.rmsnorm_fwd(h2, w[p + "post_norm.weight"], y, rstd2, t.rms_norm_eps)
             gu = torch.empty(M, 2 * I, device=dev, dtype=BF)
-            self._lin_fwd(p + "gate_up.weight", y, gu)
             act = torch.empty(M, I, device=dev, dtype=BF)
             actT = None
             if save and self.keep_act_t and self._use_t(M):
                 actT = torch.empty(I, M, device=dev, dtype=BF)  # the down-proj wgrad operand, kept until backward
-                hip.swiglu_fwd_both(gu, act, actT)
-            else:
-                hip.swiglu_fwd(gu, act)
+            # gate|up projection with SwiGLU in its epilogue (round 4): gu, act and act^T leave ONE launch; the elementwise
+            # kernel that re-read gu (4 x M*I*2 B of HBM traffic per layer) is gone.  Shapes off the 256^2 kernel and adapted
+            # (LoRA) projections take the two-kernel path below.
+            if not (self.fuse_swiglu and not self.lora and hip.gemm_swiglu_fwd(y, w[p + "gate_up.weight"], gu, act, actT)):
+                self._lin_fwd(p + "gate_up.weight", y, gu)
+                if actT is not None:
+                    hip.swiglu_fwd_both(gu, act, actT)
+                else:
+                    hip.swiglu_fwd(gu, act)
             hn = torch.empty(M, dt, device=dev, dtype=BF)
             self._lin_fwd(p + "down.weight", act, hn, resid=h2)
             if save and actT is None and self.keep_act_t and self.lora:
@@ -1075,17 +1119,23 @@ class LlavaHIP(nn.Module):
             hin, rstd1, qkv, a, lse, h2, rstd2, gu, actT = layers[i]
             layers[i] = None
             # MLP
-            dact = torch.empty(M, I, device=dev, dtype=BF)
+            dact = None
             dgu = torch.empty(M, 2 * I, device=dev, dtype=BF)
             if use_t:  # wgrad operands come out of their producers already transposed
                 if actT is None:
                     actT = torch.empty(I, M, device=dev, dtype=BF)
                     hip.swiglu_fwd_t(gu, actT)
                 self._wgrad_t(dh, None, actT, p + "down.weight")
-                self._dgrad(dh, p + "down.weight", dact)
                 del actT
                 dguT = torch.empty(2 * I, M, device=dev, dtype=BF)
-                hip.swiglu_bwd_t(gu, dact, dgu, dguT)
+                # down-projection dgrad with the SwiGLU backward in its epilogue (round 4): dact never reaches HBM, dgu and
+                # dgu^T leave the GEMM (7 x M*I*2 B of elementwise traffic per layer gone, 2 + 4 of them back as epilogue I/O)
+                wdn = p + "down.weight"
+                if not (self.fuse_swiglu and hip.gemm_swiglu_bwd(dh, self.wT[wdn] if wdn in self.wT else w[wdn], wdn in self.wT,
+                                                                 gu, dgu, dguT)):
+                    dact = torch.empty(M, I, device=dev, dtype=BF)
+                    self._dgrad(dh, wdn, dact)
+                    hip.swiglu_bwd_t(gu, dact, dgu, dguT)
                 del dact, gu
                 hip.rmsnorm_apply_t(h2, w[p + "post_norm.weight"], rstd2, yT)
                 self._wgrad_t(dgu, dguT, yT, p + "gate_up.weight")
@@ -1096,6 +1146,7 @@ class LlavaHIP(nn.Module):
                 if act is None:
                     act = torch.empty(M, I, device=dev, dtype=BF)
                     hip.swiglu_fwd(gu, act)
+                dact = torch.empty(M, I, device=dev, dtype=BF)
                 self._lin_bwd(p + "down.weight", dh, act, dact)
                 hip.swiglu_bwd(gu, dact, dgu)
                 del act, dact, gu
@@ -1139,7 +1190,7 @@ class LlavaHIP(nn.Module):
         dimg = None
         clip_saved = None
         if "vis" in saved:
-            feats, p1, p1a, clip_saved, n_img = saved["vis"]
+            feats, p1, p1a, clip_saved, n_img, vis_extra = saved["vis"]
             dimg = torch.zeros(p1.shape[0], dt, device=dev, dtype=BF)
         if self._embed_scratch is None:
             self._embed_scratch = torch.zeros(V, dt, device=dev, dtype=torch.float32)
@@ -1163,7 +1214,7 @@ class LlavaHIP(nn.Module):
             if full:
                 hip.colsum(dp1, cpart, g["projector.linear_1.bias"], True)
             if vlora:
-                self._vision_backward(clip_saved, dfeats, n_img)
+                self._vision_backward(clip_saved, dfeats, n_img, vis_extra)
         if hook:  # everything else: projector, token embedding, the CLIP tower's adapters
             below = [self.range_of(n) for n in self._toff
                      if n.startswith("projector.") or n.startswith("text.embed_tokens") or n.startswith("vision.")]

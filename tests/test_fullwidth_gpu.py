@@ -113,9 +113,16 @@ def _run_hip(dev, cfg, P, Pt, loss_type, inputs, sw, lora=None):
         hip.gemm_set_tail_split(1)
 
 
-def _check(tag, got, ref):
+def _check(tag, got, ref, skip_rows=None):
+    """skip_rows: {tensor name: row indices left out of that tensor's gradient comparison} (see test_npo_full_width_vs_oracle)."""
     loss, logits, grads = got
     rloss, rlogits, rgrads, e_bf16, scale = ref
+    if skip_rows:
+        grads, rgrads = dict(grads), dict(rgrads)
+        for k, rows in skip_rows.items():
+            keep = torch.ones(rgrads[k].shape[0], dtype=torch.bool)
+            keep[list(rows)] = False
+            grads[k], rgrads[k] = grads[k][keep], rgrads[k][keep]
     assert abs(loss - rloss) < 1e-3 * max(1.0, abs(rloss), scale), (tag, loss, rloss, scale)
     el = _relerr(logits.reshape(rlogits.shape), rlogits)
     assert el < max(1e-2, 1.1 * e_bf16), (tag, "logits", el, "HF-bf16 path", e_bf16)
@@ -267,3 +274,150 @@ def test_hf_full_width_golden_slice(dev):
         name = k[len("gradnorm."):]
         gn, rn = model.g[name].float().norm().item(), float(g[k])
         assert abs(gn - rn) < 2e-2 * rn, (name, gn, rn)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# Round 4: the three BASELINE configs that had oracle numbers at tiny width only
+# ------------------------------------------------------------------------------------------------------------------------
+def test_npo_full_width_vs_oracle(dev):
+    """BASELINE config 4 at LLaVA-1.5-7B width: npo (mm/trainer.py:343-353) = (2/beta) * mean over ALL B*S*V softmax entries
+    of log(1 + (p / (p_T + 1e-8))^beta), student + frozen full-width teacher, V 32064, left padding on one row — the NPO
+    mode of the row-loss kernels on real logits (round 3 compared it with another HIP path at this width)."""
+    cfg = _cfg("7b")
+    S, B = cfg.vision.num_patches + 128, 3
+    P = init_params(cfg, seed=14)
+    Pt = teacher_params_from(P, seed=9)
+    inputs = {"forget": make_split(cfg, B, S, seed=611, n_question=40, left_pad=[0, 21, 0]),
+              "retain": make_split(cfg, B, S, seed=612, n_question=30)}
+    ref = _oracle(cfg, P, Pt, "npo", inputs)
+    valid = inputs["forget"]["attention_mask"].bool()
+    for name, sw in CONFIGS[:2]:
+        loss, logits, grads = _run_hip(dev, cfg, P, Pt, "npo", inputs, sw)
+        # the loss is ONE mean of ~2 ln 2 (not a difference of cross-entropies): bounded relative to itself, scale 0.
+        # Padded QUERY rows: npo averages over every B*S row, padding included (mm/trainer.py:348-353 has no mask), so what the
+        # model computes at a padded position matters to this loss.  There every key is masked: the oracle restates HF's eager
+        # attention (finfo.min fill -> a uniform average over all keys), the reference's configured flash_attention_2
+        # (mm/forget.py:86) returns zeros for those rows, and so do the HIP kernels.  The 21 padded positions all carry the
+        # pad id, so their (differently directed) gradients pile up in ONE embedding row: that row is left out of the
+        # comparison; every other tensor and row is held to the common bound.
+        pad_id = int(inputs["forget"]["input_ids"][1, 0])
+        assert int(inputs["forget"]["attention_mask"][1, 0]) == 0
+        w = _check(f"7b/{name}", (loss, logits[valid], grads), (ref[0], ref[1][valid], ref[2], ref[3], 0.0),
+                   skip_rows={"text.embed_tokens.weight": [pad_id]})
+        print(f"[fullwidth 7b npo {name}] loss {loss:+.6f} vs {ref[0]:+.6f}; logits {w[2]:.2e} (HF-bf16 {w[3]:.2e}); "
+              f"worst grad {w[0]} {w[1]:.2e}")
+
+
+def test_scrub_full_width_vs_oracle(dev):
+    """BASELINE config 5's second loss at LLaVA-1.5-13B width: scrub (mm/trainer.py:231-257) = -beta KL_f + KL_r + CE_r with
+    the TEACHER as kl_div's input and the student as its target (the KL_TEACHER_INPUT mode of the row-loss kernels), two
+    student and two teacher forwards, d 5120 / I 13824 / 40 heads."""
+    cfg = _cfg("13b")
+    S, B = cfg.vision.num_patches + 128, 3
+    P = init_params(cfg, seed=15)
+    Pt = teacher_params_from(P, seed=10)
+    inputs = {"forget": make_split(cfg, B, S, seed=621, n_question=40, left_pad=[0, 0, 13]),
+              "retain": make_split(cfg, B, S, seed=622, n_question=30, left_pad=[7, 0, 0])}
+    ref = _oracle(cfg, P, Pt, "scrub", inputs)
+    valid = inputs["retain"]["attention_mask"].bool()
+    for name, sw in CONFIGS[:2]:
+        loss, logits, grads = _run_hip(dev, cfg, P, Pt, "scrub", inputs, sw)
+        w = _check(f"13b/{name}", (loss, logits[valid], grads), (ref[0], ref[1][valid], ref[2], ref[3], ref[4]))
+        print(f"[fullwidth 13b scrub {name}] loss {loss:+.5f} vs {ref[0]:+.5f}; logits {w[2]:.2e} (HF-bf16 {w[3]:.2e}); "
+              f"worst grad {w[0]} {w[1]:.2e}")
+
+
+def test_lora_grad_ascent_with_images_full_width_vs_oracle(dev):
+    """BASELINE config 2 at its real shapes: grad_ascent, LoRA r=8 alpha=32 on EVERY Linear peft would wrap — decoder, lm_head,
+    projector and the CLIP tower (mm/forget.py:126-137, utils.py:10-19) — WITH images: CLIP-L/14-336 width (d 1024, 16 heads x
+    64, 577 tokens, 2 tower layers), Llama-2-7B width, S 1088.  The tower's adapters get their gradients through
+    `_vision_backward` (LayerNorm backward, quick-GELU backward, the head_dim-64 non-causal attention backward kernels at
+    T 577).  peft is not importable: pinned to y = W x + (alpha/r) B A x through the fp32 oracle on W + (alpha/r) B A with the
+    adapters as autograd leaves (parity unpinned vs peft itself)."""
+    from multimodal_unlearning_amd.llava import LlavaHIP, LoraSpec
+    from multimodal_unlearning_amd.trainer import MMTrainerForgetting
+    from oracle.llava_ref import llava_forward
+
+    cfg = _cfg("7b")
+    S, B = cfg.vision.num_patches + 512, 2
+    P = init_params(cfg, seed=16)
+    spec = LoraSpec(r=8, alpha=32.0)
+    model = LlavaHIP(cfg, P, device=dev, lora=spec)
+    model.init_lora_(seed=3, b_std=0.02)
+    model.enable_transposed_weights()
+    assert sum(1 for w in model.lora if w.startswith("vision.")) == 4 * cfg.vision_layers_used == 8
+    inputs = {"forget": make_split(cfg, B, S, seed=631, n_question=S - 1 - cfg.vision.num_patches - 256, left_pad=[0, 9]),
+              "retain": make_split(cfg, B, S, seed=632, n_question=300)}
+    tr = MMTrainerForgetting(model=model, forget_loss="grad_ascent", teacher_model=None, loss_beta=1.0, l1_lambda=0,
+                             l0_lambda=0, l_norm_from="zero")
+    model.ensure_grad().zero_()
+    loss = tr.compute_loss(model, inputs)
+    loss.backward()
+    torch.cuda.synchronize()
+    torch.set_num_threads(16)
+    leaves = {}
+    Pe = {k: v.clone() for k, v in P.items()}
+    for wname, ad in model.lora.items():
+        A = ad.A32.detach().float().cpu().requires_grad_(True)
+        Bm = ad.BL.detach().float().cpu().requires_grad_(True)
+        leaves[wname] = (A, Bm, ad.mask.float().cpu())
+        Pe[wname] = P[wname] + spec.scaling * (Bm @ A)
+    ref = -llava_forward(cfg, Pe, **inputs["forget"])["loss"]
+    ref.backward()
+    assert abs(loss.item() - ref.item()) < 1e-3 * max(1.0, abs(ref.item())), (loss.item(), ref.item())
+    worst = {"text": ("", 0.0), "vision": ("", 0.0), "projector": ("", 0.0)}
+    for wname, (A, Bm, mask) in leaves.items():
+        base = wname[: -len(".weight")]
+        grp = "vision" if wname.startswith("vision.") else ("projector" if wname.startswith("projector.") else "text")
+        for tag, got, exp in (("A", model.g[base + ".lora_A"], A.grad), ("B", model.g[base + ".lora_B"], Bm.grad * mask)):
+            e = _relerr(got, exp)
+            if e > worst[grp][1]:
+                worst[grp] = (f"{base}.lora_{tag}", e)
+            # decoder / projector adapters: the bound of the other full-width tests; the tower's adapters sit behind the
+            # whole decoder AND the CLIP sweep in bf16 (two more layers of rounding than anything else in this file)
+            assert e < (5e-2 if grp == "vision" else 3e-2), (wname, tag, e)
+    print(f"[fullwidth 7b LoRA r8 + images] loss {loss.item():+.5f} vs {ref.item():+.5f}; worst adapter gradient: "
+          + "; ".join(f"{g} {n} {e:.2e}" for g, (n, e) in worst.items()))
+
+
+def test_unfrozen_clip_l_tower_full_width_vs_oracle(dev):
+    """`freeze_vision_module: false` at the real widths: CLIP-L/14-336 width (d 1024, 16 x 64, 577 tokens, 2
+    tower layers, patch conv 588 -> 1024) in front of one Llama-2-7B-width layer, grad_ascent, full fine-tuning; every tower
+    gradient (Linears + biases, LayerNorm gamma / beta, class / position embeddings, patch conv) against the fp32 oracle."""
+    from multimodal_unlearning_amd.llava import LlavaHIP
+    from multimodal_unlearning_amd.trainer import MMTrainerForgetting
+    from oracle.llava_ref import llava_forward
+
+    cfg = _cfg("7b")
+    S, B = cfg.vision.num_patches + 128, 2
+    P = init_params(cfg, seed=17)
+    model = LlavaHIP(cfg, P, device=dev, freeze_vision=False)
+    model.enable_transposed_weights()
+    inputs = {"forget": make_split(cfg, B, S, seed=641, n_question=40, left_pad=[0, 5]),
+              "retain": make_split(cfg, B, S, seed=642, n_question=30)}
+    tr = MMTrainerForgetting(model=model, forget_loss="grad_ascent", teacher_model=None, loss_beta=1.0, l1_lambda=0,
+                             l0_lambda=0, l_norm_from="zero")
+    model.ensure_grad().zero_()
+    loss = tr.compute_loss(model, inputs)
+    loss.backward()
+    torch.cuda.synchronize()
+    torch.set_num_threads(16)
+    Pf = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    ref = -llava_forward(cfg, Pf, **inputs["forget"])["loss"]
+    ref.backward()
+    assert abs(loss.item() - ref.item()) < 1e-3 * max(1.0, abs(ref.item())), (loss.item(), ref.item())
+    worst = ("", 0.0)
+    for k, v in Pf.items():
+        if not k.startswith("vision."):
+            continue
+        exp = v.grad
+        if k == "vision.patch_embed.weight":
+            exp = exp.clone()
+            exp[:, cfg.vision.patch_k:] = 0
+        e = _relerr(model.g[k], exp)
+        if e > worst[1]:
+            worst = (k, e)
+        assert e < 6e-2, (k, e)
+    for k in ("lm_head.weight", "text.layers.0.down.weight", "projector.linear_1.weight"):
+        assert _relerr(model.g[k], Pf[k].grad) < 3e-2, k
+    print(f"[fullwidth unfrozen CLIP-L tower] loss {loss.item():+.5f} vs {ref.item():+.5f}; worst tower gradient {worst[0]} {worst[1]:.2e}")

@@ -1110,3 +1110,86 @@ def test_remove_image_tokens_device_path(dev):
     got = tu.remove_image_tokens(ids.to(dev), big, 99)
     pos = tu.image_token_source_rows(ids, L, 99)
     assert torch.equal(got.cpu(), big.cpu()[torch.arange(B)[:, None], pos])
+
+
+# ------------------------------------------------------------------------------------- SwiGLU inside the GEMM epilogues
+@pytest.mark.parametrize("M,I,K,with_t", [
+    (1000, 384, 512, True),     # ragged last tile row, three 128-unit groups (1.5 tile columns), one tile per workgroup
+    (4104, 2048, 256, True),    # 17 x 16 = 272 tiles > 256 CUs: persistent launch, workgroups cross a tile seam
+    (520, 128, 320, False),     # no transposed output, K not a multiple of 64
+])
+def test_gemm_swiglu_fwd_matches_gemm_plus_swiglu_kernel(dev, M, I, K, with_t):
+    """mmu_gemm_swiglu_fwd (gate|up projection with SwiGLU in the 256^2 epilogue: B rows of a tile gathered from the gate AND
+    the up half of W) == mmu_gemm_bf16 + mmu_swiglu_fwd_both, bit for bit: gu in its natural [g | u] order, act, act^T."""
+    hip.gemm_set_tile(256)
+    x, w = _randn((M, K), dev, 1.0, seed=1), _randn((2 * I, K), dev, 0.05, seed=2)
+    gu0, act0 = torch.empty(M, 2 * I, device=dev, dtype=BF), torch.empty(M, I, device=dev, dtype=BF)
+    actT0 = torch.empty(I, M, device=dev, dtype=BF)
+    hip.gemm(hip.NT, x, w, gu0)
+    hip.swiglu_fwd_both(gu0, act0, actT0)
+    gu1, act1 = torch.full_like(gu0, 7.0), torch.full_like(act0, 7.0)
+    actT1 = torch.full_like(actT0, 7.0) if with_t else None
+    assert hip.gemm_swiglu_fwd(x, w, gu1, act1, actT1)
+    torch.cuda.synchronize()
+    assert torch.equal(gu0, gu1), (gu0 != gu1).nonzero()[:5].tolist()
+    assert torch.equal(act0, act1), (act0 != act1).nonzero()[:5].tolist()
+    if with_t:
+        assert torch.equal(actT0, actT1), (actT0 != actT1).nonzero()[:5].tolist()
+    # sanity against the formula in fp32 (silu(g) rounded to bf16, then * u; bf16 result)
+    g, u = gu0[:, :I].float(), gu0[:, I:].float()
+    ref = ((g * torch.sigmoid(g)).to(BF).float() * u).to(BF)
+    assert _relerr(act1, ref) < 4e-3   # __expf vs torch.sigmoid: last-bit differences of the bf16 rounding of silu(g)
+
+
+@pytest.mark.parametrize("M,I,K,w_t", [
+    (1000, 384, 512, True),
+    (4104, 4096, 256, True),    # 17 x 16 tiles: persistent
+    (4104, 4096, 256, False),   # W_down [d, I] (no resident transposed copy): the NN layout of the same kernel
+    (520, 136, 320, True),      # I not a multiple of 64: the last column group is partly out of range
+])
+def test_gemm_swiglu_bwd_matches_gemm_plus_swiglu_kernel(dev, M, I, K, w_t):
+    """mmu_gemm_swiglu_bwd (down-projection dgrad whose output dact never leaves the registers) == mmu_gemm_bf16 +
+    mmu_swiglu_bwd_t, bit for bit: dgu [M, 2I] and dgu^T."""
+    hip.gemm_set_tile(256)
+    dh, wd = _randn((M, K), dev, 1.0, seed=3), _randn((K, I), dev, 0.05, seed=4)   # W_down [d, I]
+    gu = _randn((M, 2 * I), dev, 1.5, seed=5)
+    w = wd.t().contiguous() if w_t else wd
+    dact = torch.empty(M, I, device=dev, dtype=BF)
+    hip.gemm(hip.NT if w_t else hip.NN, dh, w, dact)
+    dgu0, dguT0 = torch.empty(M, 2 * I, device=dev, dtype=BF), torch.empty(2 * I, M, device=dev, dtype=BF)
+    hip.swiglu_bwd_t(gu, dact, dgu0, dguT0)
+    dgu1, dguT1 = torch.full_like(dgu0, 7.0), torch.full_like(dguT0, 7.0)
+    assert hip.gemm_swiglu_bwd(dh, w, w_t, gu, dgu1, dguT1)
+    dgu2 = torch.full_like(dgu0, 7.0)
+    assert hip.gemm_swiglu_bwd(dh, w, w_t, gu, dgu2, None)   # without the transposed copy (no LDS staging, no barriers)
+    torch.cuda.synchronize()
+    assert torch.equal(dgu0, dgu1), (dgu0 != dgu1).nonzero()[:5].tolist()
+    assert torch.equal(dguT0, dguT1), (dguT0 != dguT1).nonzero()[:5].tolist()
+    assert torch.equal(dgu0, dgu2)
+
+
+def test_gemm_swiglu_declines_shapes_off_the_256_kernel(dev):
+    hip.gemm_set_tile(0)
+    x, w = _randn((64, 256), dev, seed=1), _randn((256, 256), dev, seed=2)
+    gu, act = torch.empty(64, 256, device=dev, dtype=BF), torch.empty(64, 128, device=dev, dtype=BF)
+    assert hip.gemm_swiglu_fwd(x, w, gu, act, None) is False
+    with pytest.raises(hip.HipKernelError):   # I must be a multiple of 128 for the gathered B rows
+        hip.gemm_swiglu_fwd(x, _randn((208, 256), dev, seed=3), torch.empty(64, 208, device=dev, dtype=BF),
+                            torch.empty(64, 104, device=dev, dtype=BF), None)
+
+
+def test_layernorm_bwd_params_vs_torch(dev):
+    """mmu_layernorm_bwd_params (dgamma / dbeta of a LayerNorm over [M, d] rows, for the unfrozen CLIP tower) vs autograd of
+    torch.nn.functional.layer_norm on the same bf16 inputs in fp32; accumulate adds into an existing bf16 gradient."""
+    for M, d in ((577 * 3, 1024), (10, 128), (130, 256)):
+        x, dy = _randn((M, d), dev, 1.5, seed=1), _randn((M, d), dev, 0.7, seed=2)
+        w = torch.ones(d, device=dev, requires_grad=True)
+        b = torch.zeros(d, device=dev, requires_grad=True)
+        y = torch.nn.functional.layer_norm(x.float(), (d,), w, b, 1e-5)
+        y.backward(dy.float())
+        dg = torch.zeros(d, device=dev, dtype=BF)
+        db = torch.zeros(d, device=dev, dtype=BF)
+        hip.layernorm_bwd_params(dy, x, dg, db, 1e-5, accumulate=False)
+        assert _relerr(dg, w.grad) < 4e-3 and _relerr(db, b.grad) < 4e-3, (M, d, _relerr(dg, w.grad), _relerr(db, b.grad))
+        hip.layernorm_bwd_params(dy, x, dg, db, 1e-5, accumulate=True)
+        assert _relerr(dg, 2 * w.grad) < 8e-3 and _relerr(db, 2 * b.grad) < 8e-3

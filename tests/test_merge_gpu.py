@@ -70,13 +70,26 @@ def _mm_batches(ga, B=2, S=40):
     ("grad_ascent", None),
 ])
 def test_merged_step_matches_the_micro_batch_loop(dev, loss, loss_args):
+    from multimodal_unlearning_amd import hip
+
     ga = 3  # not a power of two: the 1/GA weights are not exact binary fractions
-    a = _run(dev, loss, True, _mm_batches(ga), loss_args=loss_args)
-    b = _run(dev, loss, False, _mm_batches(ga), loss_args=loss_args)
+    # One GEMM kernel for every shape: the tile heuristic looks at M, the 128^2 and 256^2 kernels accumulate K in different
+    # MFMA shapes, and a bf16 logit that rounds the other way moves a CE term by 1e-3 — with the same kernel a row's logits
+    # do not depend on how many other rows the batch holds, and the losses can be compared at fp32 summation-order level.
+    hip.gemm_set_tile(128)
+    try:
+        a = _run(dev, loss, True, _mm_batches(ga), loss_args=loss_args)
+        b = _run(dev, loss, False, _mm_batches(ga), loss_args=loss_args)
+    finally:
+        hip.gemm_set_tile(0)
     assert a[3] == [[ga], [ga]] and b[3] == [[1] * ga, [1] * ga], (a[3], b[3])
-    for la, lb in zip(a[0], b[0]):
-        tol = 1e-6 * max(1.0, abs(lb)) if loss != "grad_diff_forget_entropy_retain_kl" else 1e-5 * max(1.0, abs(lb))
-        assert abs(la - lb) <= tol, (loss, la, lb)
+    # step 0 runs on identical parameters: the merged loss is the looped one up to fp32 summation order.  After the first
+    # AdamW update (+-lr per element whatever the gradient's size: a sign flip of a near-zero bf16 gradient moves an element by
+    # 2 lr) the two runs hold slightly different parameters, and their losses agree to the package's 1e-3 bound only.
+    tol0 = (1e-6 if loss != "grad_diff_forget_entropy_retain_kl" else 1e-5) * max(1.0, abs(b[0][0]))
+    assert abs(a[0][0] - b[0][0]) <= tol0, (loss, a[0][0], b[0][0])
+    for la, lb in zip(a[0][1:], b[0][1:]):
+        assert abs(la - lb) <= 1e-3 * max(1.0, abs(lb)), (loss, la, lb)
     moved = (b[1] - b[2]).norm()
     assert moved > 1e-3 * b[2].norm()                                   # the steps did move the parameters
     err = (a[1] - b[1]).norm()
@@ -85,6 +98,17 @@ def test_merged_step_matches_the_micro_batch_loop(dev, loss, loss_args):
     # AdamW's first updates are +-lr per element whatever the gradient's size, so a sign flip of a near-zero bf16 gradient
     # moves an element by 2 lr: bound the share of the update that differs, not element equality
     assert err < 0.12 * moved, (float(err), float(moved))
+
+
+def test_merged_step_under_the_default_tile_heuristic(dev):
+    """The same comparison with the kernels the heuristic picks for each M (what the step runs): the merged batch may run
+    other GEMM kernels than its parts, so logits agree to bf16 rounding and the loss to the package's 1e-3 bound."""
+    for loss in ("grad_diff_forget_ce_retain_ce", "KL"):
+        a = _run(dev, loss, True, _mm_batches(3))
+        b = _run(dev, loss, False, _mm_batches(3))
+        for la, lb in zip(a[0], b[0]):
+            assert abs(la - lb) < 1e-3 * max(1.0, abs(lb)), (loss, la, lb)
+        assert (a[1] - b[1]).norm() < 2e-3 * b[1].norm()
 
 
 def test_merged_groups_follow_the_token_budget(dev):
@@ -134,8 +158,8 @@ def test_text_trainer_merges_tuple_micro_batches(dev):
         a = _run(dev, loss, True, mbs_of, text=True)
         b = _run(dev, loss, False, mbs_of, text=True)
         assert a[3] == [[2], [2]] and b[3] == [[1, 1], [1, 1]]
-        for la, lb in zip(a[0], b[0]):
-            assert abs(la - lb) <= 1e-6 * max(1.0, abs(lb)), (loss, la, lb)
+        assert abs(a[0][0] - b[0][0]) <= 1e-6 * max(1.0, abs(b[0][0])), (loss, a[0][0], b[0][0])
+        assert abs(a[0][1] - b[0][1]) <= 1e-3 * max(1.0, abs(b[0][1])), (loss, a[0][1], b[0][1])
         assert (a[1] - b[1]).norm() < 0.12 * (b[1] - b[2]).norm()
     c = _run(dev, "idk", True, mbs_of, text=True, steps=1)   # one mean over cat(forget, retain): not a per-segment mean
     assert c[3] == [[1, 1]]

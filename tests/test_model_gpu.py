@@ -562,6 +562,118 @@ def test_keep_act_t_is_equivalent(dev):
     assert torch.equal(res[0][1], res[1][1])
 
 
+def test_unfrozen_vision_tower_vs_oracle(dev):
+    """`freeze_vision_module: false` (mm/forget.py:117-118, config/mm/forget.yaml:57): in full fine-tuning the CLIP tower trains
+    with everything else.  Loss and EVERY gradient tensor — the tower's Linears and biases, LayerNorm gamma / beta, class and
+    position embeddings, the patch conv — against the fp32 oracle with requires_grad on vision.*; then one engine step moves
+    the tower's parameters and leaves the zero-padded tail of the patch-conv weight at zero."""
+    from multimodal_unlearning_amd.engine import ForgetEngine
+    from multimodal_unlearning_amd.llava import LlavaHIP
+    from multimodal_unlearning_amd.trainer import MMTrainerForgetting
+    from oracle.forget_losses_ref import compute_loss_ref
+    from oracle.llava_ref import llava_forward
+
+    cfg = tiny_test_config()
+    P = init_params(cfg, seed=0)
+    model = LlavaHIP(cfg, P, device=dev, freeze_vision=False)
+    assert model.train_vision and model.frozen_flat.numel() == 0
+    assert model.train_flat.numel() >= sum(v.numel() for v in P.values())
+    inputs = make_forget_batch(cfg, 3, 40, seed=41, n_question=7)
+    tr = MMTrainerForgetting(model=model, forget_loss="grad_diff_forget_ce_retain_ce", teacher_model=None, loss_beta=1.0,
+                             l1_lambda=0, l0_lambda=0, l_norm_from="zero")
+    model.ensure_grad().zero_()
+    loss = tr.compute_loss(model, inputs)
+    loss.backward()
+    torch.cuda.synchronize()
+    Pf = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    ref = compute_loss_ref("grad_diff_forget_ce_retain_ce", lambda x: llava_forward(cfg, Pf, **x), None, inputs, 1.0)
+    ref.backward()
+    assert abs(loss.item() - ref.item()) < 1e-3 * max(1.0, abs(ref.item())), (loss.item(), ref.item())
+    worst = ("", 0.0)
+    num = den = 0.0
+    for k, v in Pf.items():
+        got, exp = model.g[k].float().cpu(), v.grad
+        if k == "vision.patch_embed.weight":  # the zero-padded tail columns are not parameters
+            assert float(got[:, cfg.vision.patch_k:].abs().max()) == 0.0
+            exp = exp.clone()
+            exp[:, cfg.vision.patch_k:] = 0
+        e = _relerr(got, exp)
+        if k.startswith("vision.") and e > worst[1]:
+            worst = (k, e)
+        num += float((got - exp).pow(2).sum())
+        den += float(exp.pow(2).sum())
+        # the tower sits behind the whole decoder in bf16; single small vectors (LayerNorm betas of 128 entries) are the noisiest
+        assert e < (6e-2 if k.startswith("vision.") else 3e-2), (k, e)
+    assert (num / den) ** 0.5 < 2e-2
+    print(f"[unfrozen tower] loss {loss.item():+.5f} vs {ref.item():+.5f}; worst vision gradient {worst[0]} {worst[1]:.2e}")
+    # frozen tower on the same inputs: identical loss, identical gradients for everything outside the tower
+    frozen = LlavaHIP(cfg, P, device=dev)
+    trf = MMTrainerForgetting(model=frozen, forget_loss="grad_diff_forget_ce_retain_ce", teacher_model=None, loss_beta=1.0,
+                              l1_lambda=0, l0_lambda=0, l_norm_from="zero")
+    frozen.ensure_grad().zero_()
+    lf = trf.compute_loss(frozen, inputs)
+    lf.backward()
+    # (the frozen sweep runs the tower's fc1 with quick-GELU in the GEMM epilogue, the trainable sweep as GEMM + kernel with
+    # the pre-activation kept: same rounding points, so these are expected to agree to the last bit — bounded, not asserted)
+    assert abs(float(lf) - float(loss)) <= 1e-6 * max(1.0, abs(float(loss)))
+    for k in frozen.g:
+        assert _relerr(model.g[k], frozen.g[k]) < 1e-3, k
+    eng = ForgetEngine(model, tr, ForgetConfig(lr=1e-3), total_steps=10, warmup_steps=0)
+    before = {k: model.w[k].detach().clone() for k in ("vision.layers.0.qkv.weight", "vision.pre_ln.bias", "vision.class_embedding",
+                                                       "vision.position_embedding", "vision.patch_embed.weight")}
+    model.ensure_grad().zero_()
+    eng.step([inputs])
+    for k, v in before.items():
+        assert not torch.equal(model.w[k], v), k
+    assert float(model.w["vision.patch_embed.weight"][:, cfg.vision.patch_k:].abs().max()) == 0.0
+
+
+def test_forget_entry_point_accepts_an_unfrozen_tower(dev, tmp_path):
+    from multimodal_unlearning_amd.forget import ForgetRunConfig, parse_overrides, run
+
+    base = ["model_family=tiny", "forget_data_path=synthetic:8", "batch_size=2", "gradient_accumulation_steps=1", "seq_len=40",
+            "num_epochs=1", "lr=1e-3", "save_model=false"]
+    e = run(parse_overrides(base + [f"save_dir={tmp_path / 'a'}", "freeze_vision_module=false"], ForgetRunConfig()))
+    assert e.model.train_vision and "vision.layers.0.fc1.weight" in e.model.trainable_names()
+    e = run(parse_overrides(base + [f"save_dir={tmp_path / 'b'}", "freeze_vision_module=false", "LoRA.r=8"], ForgetRunConfig()))
+    assert not e.model.train_vision and e.model.lora          # peft freezes every base weight: only the adapters train
+    e = run(parse_overrides(base + [f"save_dir={tmp_path / 'c'}"], ForgetRunConfig()))
+    assert not e.model.train_vision and "vision.layers.0.fc1.weight" not in e.model.trainable_names()
+
+
+def test_swiglu_in_the_gemm_epilogues_is_equivalent(dev):
+    """SwiGLU forward in the gate|up GEMM's epilogue and SwiGLU backward in the down-projection dgrad's
+    epilogue (llava.fuse_swiglu) give the same loss and gradients, bit for bit, as the GEMM + elementwise-kernel path, with
+    and without act^T kept from the forward, with and without the resident W^T copies."""
+    from multimodal_unlearning_amd import hip
+    from multimodal_unlearning_amd.llava import LlavaHIP
+    from multimodal_unlearning_amd.trainer import MMTrainerForgetting
+
+    cfg = tiny_test_config()
+    inputs = make_forget_batch(cfg, 8, 72, seed=31, n_question=9)   # 2 x 8 x 72 = 1152 rows >= transposed_wgrad_min_m
+    hip.gemm_set_tile(256)  # the tiny widths would otherwise run on the 128^2 kernel, which has no fused epilogue
+    try:
+        for wt in (False, True):
+            model = LlavaHIP(cfg, init_params(cfg, seed=0), device=dev)
+            if wt:
+                model.enable_transposed_weights()
+            tr = MMTrainerForgetting(model=model, forget_loss="grad_diff_forget_ce_retain_ce", teacher_model=None,
+                                     loss_beta=1.0, l1_lambda=0, l0_lambda=0, l_norm_from="zero")
+            res = {}
+            for keep in (False, True):
+                for fuse in (False, True):
+                    model.keep_act_t, model.fuse_swiglu = keep, fuse
+                    model.ensure_grad().zero_()
+                    loss = tr.compute_loss(model, inputs)
+                    loss.backward()
+                    res[keep, fuse] = (float(loss), model.ensure_grad().clone())
+            for keep in (False, True):
+                assert res[keep, True][0] == res[keep, False][0], (wt, keep)
+                assert torch.equal(res[keep, True][1], res[keep, False][1]), (wt, keep)
+    finally:
+        hip.gemm_set_tile(0)
+
+
 def test_l1l0_regulariser_hip_kernels(models):
     """mm/trainer.py:451-481 through the HIP kernels: value == torch.norm(p=1/0) of bf16(p - teacher) (fp64 reference),
     gradient == lambda1 * upstream * sign(d) accumulated into the flat gradient (exact in bf16), L0 without gradient."""
@@ -917,7 +1029,7 @@ def test_hosted_trainer_uses_the_fused_optimiser_with_hf_decay_groups(dev, optim
     def engine_run():
         ref = LlavaHIP(cfg, P, device=dev)
         eng = ForgetEngine(ref, MMTrainerForgetting(model=ref, **kw), ForgetConfig(lr=lr, weight_decay=wd, max_grad_norm=1e9),
-                           total_steps=2, warmup_steps=0, transposed_weights=False,
+                           total_steps=2, warmup_steps=0, transposed_weights=False, merge_ga=False,  # HF walks the micro-batches
                            optimizer="adamw8bit" if "8bit" in optim else "adamw")
         eng.step(data[0:2])
         eng.step(data[2:4])
@@ -1181,8 +1293,10 @@ def test_hosted_trainer_matches_the_engine_with_lora_and_on_the_text_surface(dev
 
     InOrder(model=model, args=args, train_dataset=data, data_collator=lambda x: x[0], **kw).train()
     ref = new_model()
+    # merge_ga=False: HF's loop walks the micro-batches one by one; the merged sweep (tests/test_merge_gpu.py) agrees with that
+    # only up to bf16 accumulation order, and this test pins the optimiser arrangement far below that
     eng = ForgetEngine(ref, plugin(model=ref, **kw), ForgetConfig(lr=lr, weight_decay=wd, max_grad_norm=1e9), total_steps=10 ** 9,
-                       warmup_steps=0, transposed_weights=False)
+                       warmup_steps=0, transposed_weights=False, merge_ga=False)
     eng.step(data[0:2])
     eng.step(data[2:4])
     start = new_model().train_flat.detach().float()
