@@ -31,7 +31,7 @@ import torch.distributed as dist  # noqa: E402
 PEAK_BF16 = 2.5e15  # dense bf16 MFMA FLOP/s per MI355X
 
 
-def flops_per_sample(cfg, S, paired=True, lora=False, text_only=False, forward_only=False, head_rows=None):
+def flops_per_sample(cfg, S, paired=True, lora=False, text_only=False, forward_only=False, head_rows=None, recompute=False):
     """FLOPs of one grad_diff full-FT sample (forget + retain sequence), vision tower frozen: matmul = 2mnk, causal
     attention at half the dense S^2.  head_rows: rows per sequence that go through the lm_head
     (None = all S positions, SURVEY §8d's algorithmic count; the loss-only forward runs the supervised rows only and
@@ -54,6 +54,8 @@ def flops_per_sample(cfg, S, paired=True, lora=False, text_only=False, forward_o
     # LoRA: dgrad only (adapter GEMMs are < 1 %), including the dgrad sweep through the adapted CLIP tower (BASELINE.md
     # §2: 30.16 T per sequence); full fine-tuning: dgrad + wgrad of decoder and projector, CLIP frozen (no backward)
     fb = fwd + ((dec + proj + clip) if lora else 2 * (dec + proj))
+    if recompute:  # gradient checkpointing: every decoder layer's forward runs a second time inside the backward sweep
+        fb += lin + attn
     return (2 if paired else 1) * fb
 
 
@@ -435,6 +437,9 @@ def main():
                          "stream for --squat-ms, standing in for RCCL's all-reduce kernels (tests/c_abi/squatter.hip)")
     ap.add_argument("--squat-ms", type=float, default=80.0)
     ap.add_argument("--no-fuse", action="store_true")
+    ap.add_argument("--recompute", action="store_true",
+                    help="gradient checkpointing (mm/forget.py:123-124): keep one tensor per decoder layer, re-run the layer's "
+                         "forward in backward (+1/3 FLOPs, executed and priced)")
     ap.add_argument("--no-merge-ga", action="store_true",
                     help="A/B: walk the gradient-accumulation micro-batches one by one (round-3 behaviour); default: micro-batches "
                          "that fit HBM together run as ONE concatenated forward/backward (ForgetEngine._groups)")
@@ -523,6 +528,7 @@ def main():
     n_seq = B * (2 if (len(splits) >= 2 and not args.no_fuse and args.loss.lower() in ("grad_diff_forget_ce_retain_ce", "eco_ft", "idk")) else 1)
     act_t_bytes = n_seq * (cfg.vision.num_patches + 512) * cfg.text.intermediate_size * 2 * cfg.text.num_layers
     model.keep_act_t = bool(args.keep_act_t) if args.keep_act_t is not None else (args.model == "7b" and act_t_bytes <= 24e9)
+    model.recompute_activations = bool(args.recompute)
     if args.text_only:
         from multimodal_unlearning_amd.synthetic import make_text_split
 
@@ -608,7 +614,8 @@ def main():
             from multimodal_unlearning_amd.llava import supervised_rows
             head_rows = (supervised_rows(mbs[0]["forget"]["labels"].cpu(), cfg.text.vocab_size, "cpu")[2] + S) / 2
         fps_alg = flops_per_sample(cfg, S, paired=paired, lora=bool(args.lora_r), text_only=args.text_only)
-        fps = flops_per_sample(cfg, S, paired=paired, lora=bool(args.lora_r), text_only=args.text_only, head_rows=head_rows)
+        fps = flops_per_sample(cfg, S, paired=paired, lora=bool(args.lora_r), text_only=args.text_only, head_rows=head_rows,
+                               recompute=args.recompute)
         # teacher forwards (no grad): npo 1, kl 1, scrub 2, grad_diff_*_kl 1 per kl side
         t_fwd = {"npo": 1, "kl": 1, "scrub": 2, "llmu": 1}.get(lt, lt.count("_kl") if lt.startswith("grad_diff") else 0)
         if t_fwd:
@@ -652,7 +659,7 @@ def main():
                        "ga_groups": headline_groups,
                        "optimizer": ("AdamW fp32 moments" if args.optim == "adamw" else "AdamW block-wise 8-bit moments") + ", clip 1.0",
                        "lora_r": args.lora_r,
-                       "keep_act_t": model.keep_act_t,
+                       "keep_act_t": model.keep_act_t, "gradient_checkpointing": bool(args.recompute),
                        "reference_batch_value": (None if ref_batch is None else
                                                  {"micro_batch_pairs_per_gpu": 2, "grad_accum": GA, "ga_groups": list(eng.last_groups),
                                                   "samples_per_s": round(ref_batch, 4),

@@ -14,7 +14,7 @@
 extern "C" {
 #endif
 
-/* ABI version, bumped on any signature change. */
+/* ABI version, bumped on any signature change or added entry point (4 = round 4: additions only). */
 int mmu_abi_version(void);
 
 /* ---- GEMM (nn.Linear fwd / dgrad / wgrad reached from mm/trainer.py:180-433 `model(**inputs)` and the
@@ -74,9 +74,13 @@ int mmu_gemm_set_xcd_map(int mode);
  * mmu_gemm_set_tile_queue, without it mode 1 launches one workgroup per tile.  0 = one workgroup per tile.
  * 2 = persistent with a static tile walk (A/B tests: degrades badly when CUs are shared). */
 int mmu_gemm_set_persistent(int mode);
-/* Tile-queue counters of the persistent launch: device memory of >= mmu_gemm_tile_queue_bytes() (4 KiB), 16-B aligned,
- * ZERO when registered (the kernels leave it zero); NULL unregisters.  The library never allocates. */
+/* Tile-queue counters of the persistent launch: device memory of >= mmu_gemm_tile_queue_bytes() (4 KiB), 16-B aligned;
+ * the call zeroes it (memset + device synchronise: a set-up step) and the kernels leave it zero; NULL unregisters (launches
+ * with more tiles than CUs then run one workgroup per tile).  The library never allocates. */
 int mmu_gemm_set_tile_queue(void* counters, long long bytes);
+/* Clears the registered tile-queue counters after a device synchronise: call it after a GEMM launch reported an error (or a
+ * kernel fault was handled) so that a half-drawn queue slot cannot make later launches skip tiles.  No-op without a queue. */
+int mmu_gemm_reset_tile_queue(void);
 long long mmu_gemm_tile_queue_bytes(void);
 /* Split-K tail of the 256x256 kernel: when the last (tiles % 256) tiles fill at most half a round of the 256 CUs, each
  * is cut into 256 / remainder K ranges on extra workgroups (fp32 partials in the workspace, reduced by a fold
@@ -141,6 +145,11 @@ int mmu_layernorm_bwd(const void* dy, const void* x, const void* w, const void* 
  * 2 * M floats, part 2 * mmu_colsum_nparts(M) * d floats. */
 int mmu_layernorm_bwd_params(const void* dy, const void* x, float* stats, float* part, void* dgamma, void* dbeta,
                              int accumulate, int M, int d, float eps, void* stream);
+
+/* peft's lora_dropout (mm/forget.py:128-136; nn.Dropout on the adapter's input): y[i] = x[i] / (1 - p) where a counter-based
+ * hash of (seed, i) keeps the element, else 0.  The backward regenerates the mask from the seed (same call on the gradient);
+ * in place allowed; n % 8 == 0.  The bit stream is the library's own, not torch's Philox stream (parity unpinned vs peft). */
+int mmu_dropout_bf16(const void* x, void* y, long long n, float p, unsigned long long seed, void* stream);
 int mmu_quick_gelu_fwd(const void* x, void* y, long long n, void* stream);
 int mmu_quick_gelu_bwd(const void* x, const void* dy, void* dx, long long n, void* stream);
 int mmu_head_pad(const void* src, int ld_src, int d_src, void* dst, int ld_dst, int d_dst, int M, int H, void* stream);

@@ -63,7 +63,8 @@ def unused_hf_tensor_shapes(cfg: LlavaConfig, style: str):
 
 
 def save_pretrained(cfg: LlavaConfig, params, out_dir: str, style: str = "hf4", max_shard_bytes: int = 5 << 30,
-                    dtype=torch.bfloat16, lora_state=None, extra=None, lora_r: int = 8, lora_alpha: float = 32.0):
+                    dtype=torch.bfloat16, lora_state=None, extra=None, lora_r: int = 8, lora_alpha: float = 32.0,
+                    lora_dropout: float = 0.0):
     """`model.save_pretrained(save_dir)` (mm/forget.py:193-195) for the replica: safetensors shards with transformers'
     tensor names, `config.json` (LlavaConfig) and `generation_config.json`, so the reference's eval
     (`from_pretrained(save_dir)`, mm/eval.py) loads the directory with no missing key.  `extra`: the HF tensors
@@ -109,7 +110,7 @@ def save_pretrained(cfg: LlavaConfig, params, out_dir: str, style: str = "hf4", 
     mc["hf_tensor_names"], mc["synthesized_keys"] = style, synthesized
     json.dump(mc, open(os.path.join(out_dir, "mmu_config.json"), "w"), indent=2)
     if lora_state:
-        save_adapter(cfg, lora_state, out_dir, r=lora_r, alpha=lora_alpha, style=style)
+        save_adapter(cfg, lora_state, out_dir, r=lora_r, alpha=lora_alpha, style=style, dropout=lora_dropout)
     return sorted(set(weight_map.values()))
 
 
@@ -188,12 +189,12 @@ def lora_state_from_peft(cfg: LlavaConfig, sd, bases, style: str | None = None):
     return out
 
 
-def save_adapter(cfg: LlavaConfig, state, out_dir: str, r: int, alpha: float, style: str = "hf4"):
+def save_adapter(cfg: LlavaConfig, state, out_dir: str, r: int, alpha: float, style: str = "hf4", dropout: float = 0.0):
     """peft-layout adapter directory: adapter_model.safetensors + the fields of adapter_config.json we use."""
     os.makedirs(out_dir, exist_ok=True)
     save_file({k: v.contiguous() for k, v in lora_state_to_peft(cfg, state, style).items()},
               os.path.join(out_dir, "adapter_model.safetensors"))
-    json.dump({"peft_type": "LORA", "r": r, "lora_alpha": alpha, "lora_dropout": 0.0, "bias": "none",
+    json.dump({"peft_type": "LORA", "r": r, "lora_alpha": alpha, "lora_dropout": float(dropout), "bias": "none",
                "task_type": "CAUSAL_LM"}, open(os.path.join(out_dir, "adapter_config.json"), "w"), indent=2)
 
 

@@ -589,6 +589,28 @@ __global__ void layernorm_dwdb_kernel(const bf16* __restrict__ dy, const bf16* _
     part[((size_t)nparts + blockIdx.y) * d + j] = sb;
 }
 
+// Dropout (peft's `lora_dropout`, mm/forget.py:128-136: nn.Dropout on the ADAPTER's input, y = W x + (alpha/r) B A drop(x)):
+// y[i] = keep(i) ? x[i] / (1 - p) : 0 with keep(i) a counter-based hash of (seed, i), so the backward pass regenerates the
+// same mask from the seed instead of storing it (the same kernel masks the gradient).  In place (y == x) is allowed.
+// The bit stream is this library's own (a 64-bit mix of seed and element index), not torch's Philox stream.
+__device__ __forceinline__ unsigned dropout_bits(unsigned long long seed, unsigned long long i) {
+    unsigned long long z = seed + i * 0x9E3779B97F4A7C15ull;   // splitmix64 of the (seed, index) pair
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (unsigned)(z >> 40);  // 24 random bits
+}
+__global__ void dropout_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, size_t nch, unsigned thresh, float scale,
+                               unsigned long long seed) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nch; i += (size_t)gridDim.x * blockDim.x) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + i * 8);
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = f2bf(dropout_bits(seed, i * 8 + j) >= thresh ? bf2f(v[j]) * scale : 0.f);
+        *reinterpret_cast<bf16x8*>(y + i * 8) = o;
+    }
+}
+
 // column-sum of a bf16 matrix [M][d] into fp32 partials (bias gradients): block handles a row range.
 __global__ void colsum_bf16_kernel(const bf16* __restrict__ x, float* __restrict__ part, int M, int d,
                                    int rows_per_block) {
@@ -933,6 +955,16 @@ extern "C" int mmu_layernorm_bwd(const void* dy, const void* x, const void* w, c
                        (const bf16*)w, (const bf16*)dres, (bf16*)dx, M, d, eps)
     if (d <= 1024) { CALL(2); } else if (d <= 2048) { CALL(4); } else { return -1; }
 #undef CALL
+    MMU_CHECK_LAUNCH();
+    return 0;
+}
+
+// y = dropout(x) with drop probability p in [0, 1): element i is kept iff hash24(seed, i) >= p * 2^24 and scaled by 1/(1-p).
+extern "C" int mmu_dropout_bf16(const void* x, void* y, long long n, float p, unsigned long long seed, void* stream) {
+    if (n <= 0 || (n & 7) || !(p >= 0.f) || !(p < 1.f)) return -1;
+    const unsigned thresh = (unsigned)(p * 16777216.0f);
+    hipLaunchKernelGGL(dropout_kernel, dim3(grid_for((size_t)n / 8, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)x,
+                       (bf16*)y, (size_t)n / 8, thresh, 1.0f / (1.0f - p), seed);
     MMU_CHECK_LAUNCH();
     return 0;
 }

@@ -1257,12 +1257,28 @@ extern "C" int mmu_gemm_set_persistent(int mode) {
     g_persist = mode;
     return 0;
 }
-// Device memory for the tile queues of the persistent launch: `bytes` >= mmu_gemm_tile_queue_bytes(), 16-B aligned and
-// ZERO when registered (the kernels leave it zero again); nullptr unregisters.  The library never allocates.
+// Device memory for the tile queues of the persistent launch: `bytes` >= mmu_gemm_tile_queue_bytes(), 16-B aligned; nullptr
+// unregisters (launches with more tiles than CUs then run one workgroup per tile).  The library never allocates.  The
+// counters must be zero whenever no launch is in flight: this call zeroes them (memset on the NULL stream + a device
+// synchronise: registration is a set-up step, not a hot path), the kernels leave them zero again, and
+// mmu_gemm_reset_tile_queue() restores that state after a launch died between its draws and its exit (a counter left
+// non-zero would make later launches skip tiles: first draws past the tile count return without computing).
 extern "C" int mmu_gemm_set_tile_queue(void* counters, long long bytes) {
     if (counters && (bytes < (long long)(g256::TQ_SLOTS * 16 * sizeof(int)) || ((uintptr_t)counters & 15))) return -1;
+    if (counters) {
+        hipError_t e = hipMemset(counters, 0, g256::TQ_SLOTS * 16 * sizeof(int));
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e != hipSuccess) return (int)e;
+    }
     g_tileq = (int*)counters;
     return 0;
+}
+extern "C" int mmu_gemm_reset_tile_queue(void) {
+    if (!g_tileq) return 0;
+    hipError_t e = hipDeviceSynchronize();  // nothing may be drawing while the counters are cleared
+    if (e == hipSuccess) e = hipMemset(g_tileq, 0, g256::TQ_SLOTS * 16 * sizeof(int));
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    return (int)e;
 }
 extern "C" long long mmu_gemm_tile_queue_bytes(void) { return (long long)(g256::TQ_SLOTS * 16 * sizeof(int)); }
 

@@ -358,4 +358,4 @@ extern "C" int mmu_scale_bf16(void* x, long long n, float s, void* stream) {
     return 0;
 }
 
-extern "C" int mmu_abi_version(void) { return 3; }
+extern "C" int mmu_abi_version(void) { return 4; }  // 4: round 4 added entry points (fused SwiGLU GEMMs, logprobs, LayerNorm parameter gradients, dropout, queue reset); no existing signature changed

@@ -46,6 +46,8 @@ class ForgetRunConfig(ForgetConfig):
     dp_mode: str = "allreduce"                  # "allreduce" | "rs_ag"
     seq_len: int = 0                            # synthetic data: 0 = 576 image + 512 text tokens (text: 500)
     max_steps: int = 0                          # 0 = the reference's formula
+    gradient_checkpointing: bool = False        # config/model_config.yaml `gradient_checkpointing` (mm/forget.py:123-124): recompute
+                                                # the decoder layers' activations in backward instead of keeping them
     modality: str = "mm"                        # "mm": mm/forget.py (image + QA pairs, MMTrainerForgetting);
                                                 # "text": nlp/forget.py (TOFU-style QA, CustomTrainerForgetting, tuple inputs)
 
@@ -273,9 +275,8 @@ def run(rc: ForgetRunConfig):
     use_lora = rc.lora_r != 0 and (rc.l_norm_from != "zero" or rc.l1_lambda == 0)
     if rc.lora_r != 0 and not use_lora:
         log(f"LoRA.r={rc.lora_r} ignored: l1_lambda={rc.l1_lambda} with l_norm_from=zero runs full fine-tuning (mm/forget.py:126)")
-    if use_lora and rc.lora_dropout != 0:
-        raise SystemExit("LoRA.dropout != 0 is not implemented (the reference's default is 0.0, config/mm/forget.yaml:6)")
-    lora = LoraSpec(r=rc.lora_r, alpha=rc.lora_alpha) if use_lora else None
+    # LoRA.dropout (config/mm/forget.yaml:6, default 0.0): peft's nn.Dropout on the adapters' input, mask stream seeded by cfg.seed
+    lora = LoraSpec(r=rc.lora_r, alpha=rc.lora_alpha, dropout=rc.lora_dropout, seed=rc.seed) if use_lora else None
     need_teacher = bool(rc.l1_lambda or rc.l0_lambda) or tu.loss_needs_teacher(lt)
     params = extra = None
     # What model_path holds is decided ONCE, by rank 0, before any rank can have written there (the merge below rewrites the
@@ -326,6 +327,8 @@ def run(rc: ForgetRunConfig):
     # trains it with everything else in full fine-tuning (under LoRA peft freezes every base weight whatever the flag says)
     model = LlavaHIP(cfg, params, device=dev, lora=lora, seed=rc.seed, init="device" if params is None else "numpy",
                      freeze_vision=bool(rc.freeze_vision_module) or text)
+    if rc.gradient_checkpointing:
+        model.gradient_checkpointing_enable()
     if not rc.freeze_vision_module and not text:
         log("vision tower: " + ("TRAINABLE (freeze_vision_module=false)" if model.train_vision else
                                 "base weights frozen by LoRA; its adapters train"))

@@ -35,6 +35,7 @@ SIGNATURES = {
     "mmu_gemm_set_tail_split": [_i],
     "mmu_gemm_set_workspace": [_vp, _ll],
     "mmu_gemm_set_tile_queue": [_vp, _ll],
+    "mmu_gemm_reset_tile_queue": [],
     "mmu_attn_fwd": [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp],
     "mmu_attn_bwd": [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i,
                      _vp],
@@ -50,6 +51,7 @@ SIGNATURES = {
     "mmu_layernorm_fwd": [_vp, _vp, _vp, _vp, _i, _i, _f, _vp],
     "mmu_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
     "mmu_layernorm_bwd_params": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
+    "mmu_dropout_bf16": [_vp, _vp, _ll, _f, C.c_ulonglong, _vp],
     "mmu_quick_gelu_fwd": [_vp, _vp, _ll, _vp],
     "mmu_quick_gelu_bwd": [_vp, _vp, _vp, _ll, _vp],
     "mmu_head_pad": [_vp, _i, _i, _vp, _i, _i, _i, _i, _vp],
@@ -130,6 +132,9 @@ def load() -> C.CDLL:
 
 def _check(rc: int, name: str):
     if rc != 0:
+        if name.startswith("mmu_gemm") and rc > 0 and _lib is not None:
+            # a GEMM launch died: a tile-queue slot may be half drawn — clear the counters before anything else runs
+            _lib.mmu_gemm_reset_tile_queue()
         raise HipKernelError(f"{name} failed with code {rc}" + (" (unsupported argument)" if rc == -1 else " (hipError)"))
 
 
@@ -450,6 +455,14 @@ def layernorm_bwd_params(dy, x, dgamma, dbeta, eps, accumulate=True):
     part = torch.empty(2 * colsum_nparts(M) * d, device=x.device, dtype=torch.float32)
     _check(load().mmu_layernorm_bwd_params(_p(dy), _p(x), _p(stats), _p(part), _p(dgamma), _p(dbeta), int(accumulate), M, d,
                                            float(eps), _stream()), "mmu_layernorm_bwd_params")
+
+
+def dropout(x, y, p, seed):
+    """y = dropout(x, p) with the mask a hash of (seed, element index): the same call on a gradient applies the same mask."""
+    _bf16c(x, y)
+    assert x.is_contiguous() and y.is_contiguous() and x.numel() == y.numel()
+    _check(load().mmu_dropout_bf16(_p(x), _p(y), x.numel(), float(p), int(seed) & (2 ** 64 - 1), _stream()), "mmu_dropout_bf16")
+    return y
 
 
 def quick_gelu_fwd(x, y):

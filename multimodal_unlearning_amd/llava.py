@@ -24,6 +24,7 @@ from __future__ import annotations
 import math
 import os
 from collections import OrderedDict
+from dataclasses import dataclass
 from typing import Callable, Dict, Optional
 
 import torch
@@ -45,9 +46,14 @@ class LoraSpec:
     `targets` makes the set explicit, as SURVEY.md §4 asks."""
 
     def __init__(self, r: int = 8, alpha: float = 32.0,
-                 targets=("qkv", "o", "gate_up", "down", "lm_head", "projector", "vision")):
+                 targets=("qkv", "o", "gate_up", "down", "lm_head", "projector", "vision"), dropout: float = 0.0, seed: int = 0):
         self.r, self.alpha, self.targets = int(r), float(alpha), tuple(targets)
         self.scaling = self.alpha / self.r
+        # peft's lora_dropout (mm/forget.py:128-136, config/mm/forget.yaml:6): nn.Dropout on the ADAPTER's input in training
+        # forwards, y = W x + (alpha/r) B A drop(x); `seed` starts the stream of per-Linear mask seeds
+        if not 0.0 <= float(dropout) < 1.0:
+            raise ValueError(f"LoRA dropout {dropout}: expected 0 <= p < 1")
+        self.dropout, self.seed = float(dropout), int(seed)
 
 
 class _Adapter:
@@ -58,11 +64,14 @@ class _Adapter:
 
 
 
+@dataclass
 class LlavaOutput:
-    """Attribute + key access like transformers' ModelOutput (`.loss`, `.logits`)."""
-
-    def __init__(self, loss=None, logits=None, hidden_states=None):
-        self.loss, self.logits, self.hidden_states = loss, logits, hidden_states
+    """Attribute + key access like transformers' ModelOutput (`.loss`, `.logits`).  A dataclass on purpose: torch DDP looks for
+    the tensors of a forward's output (to find the autograd graph when `find_unused_parameters=True`, mm/forget.py:161) in
+    tensors, lists, dicts and dataclasses only — an opaque object would read as "no parameter was used"."""
+    loss: Optional[torch.Tensor] = None
+    logits: Optional[torch.Tensor] = None
+    hidden_states: Optional[torch.Tensor] = None
 
     def __getitem__(self, k):
         return getattr(self, k)
@@ -284,11 +293,17 @@ class LlavaHIP(nn.Module):
         self.fuse_rope = os.environ.get("MMU_NO_ROPE_FUSION", "0") != "1"  # A/B switch
         self.fuse_dqkv_t = os.environ.get("MMU_NO_DQKV_T", "0") != "1"     # A/B switch: dqkv^T written by attention backward
         self.fuse_swiglu = os.environ.get("MMU_NO_SWIGLU_FUSION", "0") != "1"  # A/B switch: SwiGLU fwd / bwd in the GEMM epilogues
+        # activation recompute = the reference's `model.gradient_checkpointing_enable()` (mm/forget.py:123-124): the forward
+        # keeps one [tokens, d] tensor per decoder layer instead of ~92-114 KB per token and layer, the backward pays one more
+        # forward of every layer (+33 % FLOPs).  Buys micro-batch where HBM is the limit (13B + teacher + fp32 moments).
+        self.recompute_activations = False
         # keep act^T of every layer from forward to backward (+ layers*M*I*2 B, 23 GB at 7B / 30 sequences) instead of
         # recomputing it from gate|up in backward; the owner of the step turns it on when HBM allows (bench.py does)
         self.keep_act_t = False
         self._fwd_U = None  # LoRA: x A^T of every adapted Linear of the forward in flight (-> saved["U"])
         self._bwd_U = None
+        self._drop_seeds = None  # lora_dropout: wname -> mask seed of the forward / backward in flight (-> saved["drop"])
+        self._drop_ctr = 0
         if torch.device(device).type == "cuda":
             hip.ensure_gemm_workspace(torch.device(device))  # split-K tail partials (128 MiB, once per process)
         self.lora_splitk_min_m = 2048
@@ -322,6 +337,10 @@ class LlavaHIP(nn.Module):
         # (MMTrainerForgetting.compute_loss(..., _merge=g)): `.loss` is then the mean over the g equal row segments of each
         # segment's own mean CE — what the host loop would have averaged — instead of one mean over all tokens
         self.loss_segments = 1
+        self.autograd_grads = False   # see enable_autograd_gradients
+        self.ddp_compatible = False
+        # torch DDP broadcasts module buffers from rank 0 at every forward; the frozen CLIP weights never change
+        self._ddp_params_and_buffers_to_ignore = ["frozen_flat"]
         if self.lora:
             self.init_lora_(seed)
 
@@ -443,6 +462,7 @@ class LlavaHIP(nn.Module):
             kw.setdefault("lora_state", self.lora_state())
             kw.setdefault("lora_r", self.lora_spec.r)
             kw.setdefault("lora_alpha", self.lora_spec.alpha)
+            kw.setdefault("lora_dropout", self.lora_spec.dropout)
         return save_pretrained(self.cfg, self.w, save_dir, extra=extra, **kw)
 
     def load_lora_state_(self, state):
@@ -477,13 +497,26 @@ class LlavaHIP(nn.Module):
         if self.wT:
             self.refresh_transposed_weights()
 
+    def _adapter_input(self, wname, x):
+        """peft's lora_dropout: the adapter branch of an adapted Linear sees dropout(x) in TRAINING forwards (those that
+        build a graph, in train() mode); the base branch sees x.  The mask is a hash of a per-(forward, Linear) seed kept in
+        the forward's saved state, so the backward sweep — and a gradient-checkpointing recompute — regenerate it."""
+        seeds = self._drop_seeds
+        if seeds is None:
+            return x
+        seed = seeds.get(wname)
+        if seed is None:
+            self._drop_ctr += 1
+            seed = seeds[wname] = (self.lora_spec.seed * 0x9E3779B97F4A7C15 + self._drop_ctr * 0xD1B54A32D192ED03) & (2 ** 64 - 1)
+        return hip.dropout(x.contiguous(), torch.empty_like(x, memory_format=torch.contiguous_format), self.lora_spec.dropout, seed)
+
     def _lin_fwd(self, wname, x, out, bias=None, resid=None):
         """out = x W^T (+ bias) (+ resid), plus the fused LoRA term when `wname` carries an adapter."""
         ad = self.lora.get(wname)
         if ad is None:
             return hip.gemm(hip.NT, x, self.w[wname], out, bias=bias, resid=resid)
         U = torch.empty(x.shape[0], ad.kl, device=x.device, dtype=BF)
-        hip.gemm(hip.NT, x, ad.A32s, U)  # s * x A^T
+        hip.gemm(hip.NT, self._adapter_input(wname, x), ad.A32s, U)  # s * drop(x) A^T
         if self._fwd_U is not None:
             self._fwd_U[wname] = U  # [M,32]: kept for the adapter wgrad dB = s dy^T (x A^T) instead of re-reading x
         return hip.gemm(hip.NT, x, self.w[wname], out, bias=bias, resid=resid, lora_u=U, lora_b=ad.BL)
@@ -495,7 +528,7 @@ class LlavaHIP(nn.Module):
         U = None
         if ad is not None:
             U = torch.empty(x.shape[0], ad.kl, device=x.device, dtype=BF)
-            hip.gemm(hip.NT, x, ad.A32s, U)
+            hip.gemm(hip.NT, self._adapter_input(wname, x), ad.A32s, U)
             if self._fwd_U is not None:
                 self._fwd_U[wname] = U
         if D == 128 and self.fuse_rope and hip.gemm_rope(x, self.w[wname], qkv, pos, self._cos, self._sin, 2 * dt, lora_u=U,
@@ -521,11 +554,20 @@ class LlavaHIP(nn.Module):
         M = dy.shape[0]
         Vs = torch.empty(M, ad.kl, device=dy.device, dtype=BF)
         hip.gemm(hip.NN, dy, ad.BLs, Vs)  # s * dy B
+        seed = self._drop_seeds.get(wname) if self._drop_seeds is not None else None
         if dx is not None:
-            if wname in self.wT:
-                hip.gemm(hip.NT, dy, self.wT[wname], dx, lora_u=Vs, lora_b=ad.A32T)
-            else:
-                hip.gemm(hip.NN, dy, self.w[wname], dx, lora_u=Vs, lora_b=ad.A32T)
+            wT = wname in self.wT
+            if seed is None:   # the adapter's term s dy B A rides in the dgrad GEMM's epilogue
+                hip.gemm(hip.NT if wT else hip.NN, dy, self.wT[wname] if wT else self.w[wname], dx, lora_u=Vs, lora_b=ad.A32T)
+            else:              # lora_dropout: that term passes the forward's mask first, so it is formed on its own
+                hip.gemm(hip.NT if wT else hip.NN, dy, self.wT[wname] if wT else self.w[wname], dx)
+                dxa = torch.empty_like(dx)
+                hip.gemm(hip.NT, Vs, ad.A32T, dxa)
+                hip.dropout(dxa, dxa, self.lora_spec.dropout, seed)
+                hip.add(dx, dxa, dx)
+                del dxa
+        if seed is not None:   # the adapter saw drop(x): its A gradient is taken against the same masked input
+            x = hip.dropout(x.contiguous(), torch.empty_like(x, memory_format=torch.contiguous_format), self.lora_spec.dropout, seed)
         base = wname[: -len(".weight")]
         gA, gB = self.g[base + ".lora_A"], self.g[base + ".lora_B"]
         U = self._bwd_U.pop(wname, None) if self._bwd_U is not None else None
@@ -652,10 +694,38 @@ class LlavaHIP(nn.Module):
             return hip.gemm(hip.NT, dy, self.wT[name], out)
         return hip.gemm(hip.NN, dy, self.w[name], out)
 
+    def enable_autograd_gradients(self):
+        """Hand the gradient to autograd instead of writing `train_flat.grad` by hand — what a host that listens on the
+        parameter's AccumulateGrad node needs, i.e. torch DDP under transformers.Trainer at world > 1 (the reference's
+        arrangement: mm/trainer.py:112 under `accelerate launch`, mm/forget.py:161 ddp_find_unused_parameters=True).  The
+        backward sweeps of a micro-batch still accumulate into the private flat buffer; the LAST sweep returns that buffer as
+        the gradient of `train_flat` (earlier sweeps return None = zero), autograd adds it into `.grad`, DDP's reducer sees
+        the parameter become ready and all-reduces its buckets.  The buffer is cleared by the first forward of the next
+        micro-batch.  Costs one more parameter-sized tensor (`.grad`) and one add pass per micro-batch."""
+        self.autograd_grads = True
+        self.ddp_compatible = True
+        if self.train_flat.grad is not None and self._grad_flat is not None and \
+                self.train_flat.grad.data_ptr() == self._grad_flat.data_ptr():
+            self.train_flat.grad = None
+        return self
+
+    def train(self, mode: bool = True):
+        # a host loop calls model.train() at the start of every training step (transformers.Trainer.training_step): forwards
+        # whose graph was dropped without a backward (the dead forwards of the reference's dpo branch) must not keep the
+        # sweep counter above zero, or no later sweep would count as the last one
+        self.live_sweeps = 0
+        return super().train(mode)
+
     def ensure_grad(self):
-        """Attach the persistent flat gradient buffer as train_flat.grad (zeroed when (re)attached)."""
+        """Attach the persistent flat gradient buffer as train_flat.grad (zeroed when (re)attached).  In autograd-gradient
+        mode (`enable_autograd_gradients`) the buffer stays private: `.grad` belongs to autograd / the host."""
         if self._grad_flat is None:
             self._grad_flat = torch.zeros_like(self.train_flat.data)
+        if self.autograd_grads:
+            if not self.g:
+                for name, (off, shape) in self._toff.items():
+                    self.g[name] = self._grad_flat[off:off + math.prod(shape)].view(shape)
+            return self._grad_flat
         if self.train_flat.grad is None or self.train_flat.grad.data_ptr() != self._grad_flat.data_ptr():
             self._grad_flat.zero_()
             self.train_flat.grad = self._grad_flat
@@ -663,6 +733,13 @@ class LlavaHIP(nn.Module):
             for name, (off, shape) in self._toff.items():
                 self.g[name] = self._grad_flat[off:off + math.prod(shape)].view(shape)
         return self._grad_flat
+
+    def gradient_checkpointing_enable(self, *a, **kw):
+        """transformers' name for it (mm/forget.py:124)."""
+        self.recompute_activations = True
+
+    def gradient_checkpointing_disable(self):
+        self.recompute_activations = False
 
     def activation_bytes_per_token(self) -> int:
         """Upper estimate of the HBM one sequence position keeps alive through a training forward + backward (DESIGN.md
@@ -675,6 +752,8 @@ class LlavaHIP(nn.Module):
         if self.lora:
             per_layer += 2 * I + 2 * d  # act and the x A^T products kept for the adapter wgrads
         work = 12 * I + 24 * d
+        if self.recompute_activations:  # one layer's tensors live at a time, the rest of the depth keeps its input only
+            work, per_layer = work + per_layer, 2 * d
         return L * per_layer + work + 8 * V
 
     # ----------------------------------------------------------------------------------------- forward
@@ -735,7 +814,16 @@ class LlavaHIP(nn.Module):
         return None if full else attention_mask.to(self.device, dtype=torch.int32).contiguous()
 
     def forward(self, input_ids=None, attention_mask=None, pixel_values=None, labels=None, position_ids=None,
-                loss_only: bool = False, **_unused):
+                loss_only: bool = False, ce_segments: Optional[int] = None, hidden_layer: Optional[int] = None, **_unused):
+        """`ce_segments=n` (with labels, loss_only): `.loss` is the VECTOR of the n per-segment mean CEs of `ce_losses`;
+        `hidden_layer=i`: `.hidden_states` is the output of decoder layer i (`hidden_states()`), nothing else is computed.
+        Both exist so that every way the plug-in uses the model goes through `forward` — the one entry point a wrapper such
+        as torch DDP intercepts (mm/forget.py:161)."""
+        if hidden_layer is not None:
+            return LlavaOutput(hidden_states=self.hidden_states(hidden_layer, input_ids, attention_mask, pixel_values, position_ids))
+        if ce_segments is not None:
+            return LlavaOutput(loss=self.ce_losses(input_ids, attention_mask, pixel_values, labels, position_ids,
+                                                   n_segments=int(ce_segments)))
         g = self.loss_segments
         if loss_only and labels is not None and self.capture_layer is None:
             ce = self.ce_losses(input_ids, attention_mask, pixel_values, labels, position_ids, n_segments=g)
@@ -952,6 +1040,48 @@ class LlavaHIP(nn.Module):
             out, _ = self._forward_impl(ids, kmask, pix, pos, save=False, stop_layer=layer)
         return out
 
+    def _decoder_layer(self, i, h, y, kmask, pos, B, S, save):
+        """One LlamaDecoderLayer forward (modeling_llama.py:295-326) on [tokens, d] rows: returns (output, what the backward
+        sweep needs besides the input: rstd1, post-RoPE q|k|v, attention out, lse, post-attention residual, rstd2, gate|up,
+        act^T or None).  `y` is a [tokens, d] scratch for the two normalised inputs.  Also the recompute body of the backward
+        sweep when `recompute_activations` is on."""
+        t, w = self.cfg.text, self.w
+        dev = self.device
+        M = B * S
+        dt, I, H, D = t.hidden_size, t.intermediate_size, t.num_heads, t.head_dim
+        scale = D ** -0.5
+        p = f"text.layers.{i}."
+        rstd1 = torch.empty(M, device=dev, dtype=torch.float32)
+        hip.rmsnorm_fwd(h, w[p + "input_norm.weight"], y, rstd1, t.rms_norm_eps)
+        qkv = torch.empty(M, 3 * dt, device=dev, dtype=BF)
+        self._qkv_fwd(p + "qkv.weight", y, qkv, pos, H, D, dt)
+        a = torch.empty(M, dt, device=dev, dtype=BF)
+        lse = torch.empty(B, H, S, device=dev, dtype=torch.float32) if save else None
+        hip.attn_fwd(qkv[:, :dt], qkv[:, dt:2 * dt], qkv[:, 2 * dt:], a, lse, kmask, B, S, H, D, scale, True)
+        h2 = torch.empty(M, dt, device=dev, dtype=BF)
+        self._lin_fwd(p + "o.weight", a, h2, resid=h)
+        rstd2 = torch.empty(M, device=dev, dtype=torch.float32)
+        hip.rmsnorm_fwd(h2, w[p + "post_norm.weight"], y, rstd2, t.rms_norm_eps)
+        gu = torch.empty(M, 2 * I, device=dev, dtype=BF)
+        act = torch.empty(M, I, device=dev, dtype=BF)
+        actT = None
+        if save and self.keep_act_t and self._use_t(M):
+            actT = torch.empty(I, M, device=dev, dtype=BF)  # the down-proj wgrad operand, kept until backward
+        # gate|up projection with SwiGLU in its epilogue (round 4): gu, act and act^T leave ONE launch; the elementwise
+        # kernel that re-read gu (4 x M*I*2 B of HBM traffic per layer) is gone.  Shapes off the 256^2 kernel and adapted
+        # (LoRA) projections take the two-kernel path below.
+        if not (self.fuse_swiglu and not self.lora and hip.gemm_swiglu_fwd(y, w[p + "gate_up.weight"], gu, act, actT)):
+            self._lin_fwd(p + "gate_up.weight", y, gu)
+            if actT is not None:
+                hip.swiglu_fwd_both(gu, act, actT)
+            else:
+                hip.swiglu_fwd(gu, act)
+        hn = torch.empty(M, dt, device=dev, dtype=BF)
+        self._lin_fwd(p + "down.weight", act, hn, resid=h2)
+        if save and actT is None and self.keep_act_t and self.lora:
+            actT = act  # LoRA sweep: the row-major act is the down-proj adapter's wgrad operand (no transposed path)
+        return hn, (rstd1, qkv, a, lse, h2, rstd2, gu, actT)
+
     def _forward_impl(self, ids, kmask, pix, pos, save: bool, stop_layer: Optional[int] = None,
                       rows: Optional[torch.Tensor] = None):
         self._sync_derived()
@@ -963,6 +1093,8 @@ class LlavaHIP(nn.Module):
         assert S <= t.max_position
         saved = {"B": B, "S": S, "ids": ids, "kmask": kmask, "pos": pos, "layers": [], "stop_layer": stop_layer}
         self._fwd_U = saved.setdefault("U", {}) if (save and self.lora) else None
+        self._drop_seeds = (saved.setdefault("drop", {})
+                            if (save and self.lora and self.lora_spec.dropout > 0 and self.training) else None)
         img = None
         slot = None
         if pix is not None:
@@ -978,43 +1110,16 @@ class LlavaHIP(nn.Module):
         y = torch.empty(M, dt, device=dev, dtype=BF)
         self._last_capture = None
         for i in range(t.num_layers):
-            p = f"text.layers.{i}."
-            rstd1 = torch.empty(M, device=dev, dtype=torch.float32)
-            hip.rmsnorm_fwd(h, w[p + "input_norm.weight"], y, rstd1, t.rms_norm_eps)
-            qkv = torch.empty(M, 3 * dt, device=dev, dtype=BF)
-            self._qkv_fwd(p + "qkv.weight", y, qkv, pos, H, D, dt)
-            a = torch.empty(M, dt, device=dev, dtype=BF)
-            lse = torch.empty(B, H, S, device=dev, dtype=torch.float32) if save else None
-            hip.attn_fwd(qkv[:, :dt], qkv[:, dt:2 * dt], qkv[:, 2 * dt:], a, lse, kmask, B, S, H, D, scale, True)
-            h2 = torch.empty(M, dt, device=dev, dtype=BF)
-            self._lin_fwd(p + "o.weight", a, h2, resid=h)
-            rstd2 = torch.empty(M, device=dev, dtype=torch.float32)
-            hip.rmsnorm_fwd(h2, w[p + "post_norm.weight"], y, rstd2, t.rms_norm_eps)
-            gu = torch.empty(M, 2 * I, device=dev, dtype=BF)
-            act = torch.empty(M, I, device=dev, dtype=BF)
-            actT = None
-            if save and self.keep_act_t and self._use_t(M):
-                actT = torch.empty(I, M, device=dev, dtype=BF)  # the down-proj wgrad operand, kept until backward
-            # gate|up projection with SwiGLU in its epilogue (round 4): gu, act and act^T leave ONE launch; the elementwise
-            # kernel that re-read gu (4 x M*I*2 B of HBM traffic per layer) is gone.  Shapes off the 256^2 kernel and adapted
-            # (LoRA) projections take the two-kernel path below.
-            if not (self.fuse_swiglu and not self.lora and hip.gemm_swiglu_fwd(y, w[p + "gate_up.weight"], gu, act, actT)):
-                self._lin_fwd(p + "gate_up.weight", y, gu)
-                if actT is not None:
-                    hip.swiglu_fwd_both(gu, act, actT)
-                else:
-                    hip.swiglu_fwd(gu, act)
-            hn = torch.empty(M, dt, device=dev, dtype=BF)
-            self._lin_fwd(p + "down.weight", act, hn, resid=h2)
-            if save and actT is None and self.keep_act_t and self.lora:
-                actT = act  # LoRA sweep: the row-major act is the down-proj adapter's wgrad operand (no transposed path)
+            hn, kept = self._decoder_layer(i, h, y, kmask, pos, B, S, save)
             if save:
-                saved["layers"].append((h, rstd1, qkv, a, lse, h2, rstd2, gu, actT))
+                # gradient checkpointing (model_config.yaml `gradient_checkpointing`, mm/forget.py:123-124): only the layer's
+                # input survives the forward; the backward sweep re-runs `_decoder_layer` for everything else
+                saved["layers"].append((h,) + ((None,) * 8 if self.recompute_activations else kept))
             h = hn
             if self.capture_layer is not None and i == self.capture_layer:
                 self._last_capture = h.view(B, S, dt)
             if stop_layer is not None and i == stop_layer:
-                self._fwd_U = None
+                self._fwd_U = self._drop_seeds = None
                 return h.view(B, S, dt), saved
         if rows is not None:
             # loss-only forward: final norm + lm_head on the supervised rows only (padding slots are zero rows, their
@@ -1031,7 +1136,7 @@ class LlavaHIP(nn.Module):
             if save:
                 saved["final"] = (hc, rstdf)
                 saved["rows"] = rows
-            self._fwd_U = None
+            self._fwd_U = self._drop_seeds = None
             return logits, saved
         rstdf = torch.empty(M, device=dev, dtype=torch.float32)
         hip.rmsnorm_fwd(h, w["text.norm.weight"], y, rstdf, t.rms_norm_eps)
@@ -1039,7 +1144,7 @@ class LlavaHIP(nn.Module):
         self._lin_fwd("lm_head.weight", y, logits)
         if save:
             saved["final"] = (h, rstdf)
-        self._fwd_U = None
+        self._fwd_U = self._drop_seeds = None
         return logits.view(B, S, t.vocab_size), saved
 
     # ---------------------------------------------------------------------------------------- backward
@@ -1049,6 +1154,7 @@ class LlavaHIP(nn.Module):
         self.ensure_grad()
         g = self.g
         self._bwd_U = saved.get("U")
+        self._drop_seeds = saved.get("drop")
         B, S = saved["B"], saved["S"]
         M = B * S
         dt, I, H, D, V = t.hidden_size, t.intermediate_size, t.num_heads, t.head_dim, t.vocab_size
@@ -1118,6 +1224,10 @@ class LlavaHIP(nn.Module):
             p = f"text.layers.{i}."
             hin, rstd1, qkv, a, lse, h2, rstd2, gu, actT = layers[i]
             layers[i] = None
+            if rstd1 is None:  # gradient checkpointing: re-run the layer's forward from its input (same kernels, same bits)
+                self._fwd_U = self._bwd_U  # LoRA: the x A^T products of the recomputed Linears feed the adapter wgrads below
+                _, (rstd1, qkv, a, lse, h2, rstd2, gu, actT) = self._decoder_layer(i, hin, y, saved["kmask"], saved["pos"], B, S, True)
+                self._fwd_U = None
             # MLP
             dact = None
             dgu = torch.empty(M, 2 * I, device=dev, dtype=BF)
@@ -1228,6 +1338,8 @@ class _LlavaFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, train_flat, model: LlavaHIP, ids, kmask, pix, pos, stop_layer=None, rows=None):
+        if model.autograd_grads and model.live_sweeps == 0 and model._grad_flat is not None:
+            model._grad_flat.zero_()  # first forward of a micro-batch: what the last one accumulated has been handed to autograd
         logits, saved = model._forward_impl(ids, kmask, pix, pos, save=True, stop_layer=stop_layer, rows=rows)
         model.live_sweeps += 1
         ctx.model = model
@@ -1240,4 +1352,7 @@ class _LlavaFn(torch.autograd.Function):
         ctx.saved = None
         model.live_sweeps = max(0, model.live_sweeps - 1)
         model._backward_impl(saved, dlogits, fire_hooks=model.live_sweeps == 0)
-        return None, None, None, None, None, None, None, None
+        # autograd-gradient mode: the last sweep of the micro-batch hands the accumulated buffer to autograd (see
+        # LlavaHIP.enable_autograd_gradients); otherwise `.grad` IS that buffer and there is nothing to return
+        g = model._grad_flat if (model.autograd_grads and model.live_sweeps == 0) else None
+        return g, None, None, None, None, None, None, None

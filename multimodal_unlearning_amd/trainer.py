@@ -110,6 +110,11 @@ class _RmuForgetFn(torch.autograd.Function):
         return da, None
 
 
+def _inner(model):
+    """The module behind a wrapper (torch DDP keeps it in `.module`): attributes are read there, CALLS go through the wrapper."""
+    return getattr(model, "module", model)
+
+
 def _slice_k(v, i):
     """v[:, i] of a nested [B, K, ...] split tensor, carrying the host view of labels / masks along (a fresh view has
     none, and looking at it would cost a device sync on every call)."""
@@ -240,15 +245,11 @@ class MMTrainerForgetting:
         cat = {k: (cat_with_host if k == "attention_mask" else torch.cat)([a[k], b[k]], dim=0)
                for k in _SPLIT_KEYS if k in a and k != "labels"}
         labels = cat_with_host([a["labels"], b["labels"]], dim=0)
-        if not need_outputs and getattr(model, "supports_loss_only", False) and self.loss_only_head:
-            ce = model.ce_losses(labels=labels, n_segments=2 * g, **cat)
+        if not need_outputs and getattr(_inner(model), "supports_loss_only", False) and self.loss_only_head:
+            ce = model(labels=labels, loss_only=True, ce_segments=2 * g, **cat).loss   # through forward(): a DDP wrapper sees it
             from .llava import LlavaOutput
             return ce[:g].mean(), ce[g:].mean(), LlavaOutput(loss=None, logits=None)
-        keep, model.loss_segments = getattr(model, "loss_segments", 1), 1
-        try:
-            out = model(**cat)
-        finally:
-            model.loss_segments = keep
+        out = model(**cat)
         ce = segment_ce_losses(out.logits, labels.to(out.logits.device), 2 * g)
         return ce[:g].mean(), ce[g:].mean(), out
 
@@ -256,7 +257,7 @@ class MMTrainerForgetting:
         """`model(**split)` when only `.loss` will be read: models that understand `loss_only=True` (LlavaHIP) skip the
         logits of unsupervised positions; `need_outputs` (the caller returns the outputs) or a foreign model keep the
         full forward."""
-        if not need_outputs and getattr(model, "supports_loss_only", False) and self.loss_only_head and "labels" in split:
+        if not need_outputs and getattr(_inner(model), "supports_loss_only", False) and self.loss_only_head and "labels" in split:
             return model(**split, loss_only=True)
         return model(**split)
 
@@ -378,7 +379,7 @@ class MMTrainerForgetting:
                 self._teacher(forget_inputs)
             else:
                 outputs = idk_outputs
-            image_token_index = model.config.image_token_index
+            image_token_index = _inner(model).config.image_token_index
             idk_logits = tu.remove_image_tokens(idk_inputs["input_ids"], idk_outputs.logits, image_token_index)
             idk_loss_current = -1 * tu.get_batch_loss(idk_logits, idk_inputs["labels"])
             loss = -idk_loss_current.mean()
@@ -401,14 +402,15 @@ class MMTrainerForgetting:
             # (forget) + MSE to the teacher's activation (retain).  The hidden-state sweep stops at that layer.
             layer = int(self.loss_args.get("rmu_layer", 7))
             strip = lambda d: {k: v for k, v in d.items() if k != "labels"}
-            forget_act = model.hidden_states(layer, **strip(forget_inputs))
+            hidden = (lambda m, split: m(**strip(split), hidden_layer=layer).hidden_states)   # via forward(): see LlavaHIP.forward
+            forget_act = hidden(model, forget_inputs)
             if getattr(self, "control_vec", None) is None:
                 rand_vec = torch.rand(forget_act.shape[0], 1, forget_act.shape[-1], dtype=torch.float32,
                                       device=forget_act.device)
                 self.control_vec = rand_vec / torch.norm(rand_vec) * 300
-            retain_act = model.hidden_states(layer, **strip(retain_inputs))
+            retain_act = hidden(model, retain_inputs)
             with torch.no_grad():
-                oracle_act = self.teacher_model.hidden_states(layer, **strip(retain_inputs))
+                oracle_act = hidden(self.teacher_model, retain_inputs)
             # fused mean-over-sequence + MSE kernels on the bf16 activations (no eager substitute: the kernels reject
             # anything but device bf16).  NOTE the reference's shapes: input [B,H] vs target [B,1,H] broadcast to [B,B,H]
             ctrl = self.control_vec.to(forget_act.device, torch.float32).reshape(-1, forget_act.shape[-1]).contiguous()
@@ -428,6 +430,7 @@ class MMTrainerForgetting:
         l1, l0 = self.l1_lambda, self.l0_lambda
         if not ((l1 is not None and l1 != 0) or (l0 is not None and l0 != 0)):
             return 0.0
+        model = _inner(model)
         lora = tu.has_lora_adapter(model)
         if self.l_norm_from == "init" and not lora and self.teacher_model is None:
             raise ValueError("Teacher model is required for L1\\L0 regularization during training without LORA!")
@@ -557,14 +560,15 @@ class CustomTrainerForgetting(MMTrainerForgetting):
         elif lt == "RMU":
             layer = int(self.loss_args.get("rmu_layer", 7))
             strip = lambda d: {k: v for k, v in d.items() if k != "labels"}
-            fa = model.hidden_states(layer, **strip(f))
+            hidden = (lambda m, split: m(**strip(split), hidden_layer=layer).hidden_states)
+            fa = hidden(model, f)
             cv = self.control_vec
             if cv is None:  # the text trainer draws a new vector on every call (nlp/dataloader.py:347-354)
                 rand_vec = torch.rand(1, 1, fa.shape[-1], dtype=torch.float32, device=fa.device)
                 cv = rand_vec / torch.norm(rand_vec) * 300
-            ra = model.hidden_states(layer, **strip(r))
+            ra = hidden(model, r)
             with torch.no_grad():
-                oa = self.oracle_model.hidden_states(layer, **strip(r))
+                oa = hidden(self.oracle_model, r)
             cvec = cv.to(fa.device, torch.float32).reshape(-1).contiguous()
             loss = _MseFn.apply(fa, None, cvec) * beta + _MseFn.apply(ra, oa.contiguous(), None)
         elif lt in ("retain_ft", "grad_ascent", "scrub", "eco_ft", "dpo", "KL", "LLMU") or lt.startswith("grad_diff"):
@@ -599,14 +603,17 @@ def hosted_by_hf_trainer(plugin=MMTrainerForgetting):
 
             m = kwargs.get("model", args[0] if args else None)
             if int(os.environ.get("WORLD_SIZE", "1")) > 1 and hasattr(m, "train_flat") and not getattr(m, "ddp_compatible", False):
-                # transformers.Trainer would wrap the model in torch DDP (mm/forget.py:161 ddp_find_unused_parameters), whose
-                # reducer listens on the parameter's AccumulateGrad node; LlavaHIP's autograd edge accumulates into the
-                # flat gradient buffer by hand and returns no gradient, so DDP would never see (or reduce) anything and
-                # the replicas would drift apart silently.
-                raise RuntimeError(
-                    "hosted_by_hf_trainer() at WORLD_SIZE > 1: torch DDP cannot see LlavaHIP's hand-written gradient "
-                    "accumulation.  Run data-parallel training through multimodal_unlearning_amd.engine.ForgetEngine "
-                    "(python -m multimodal_unlearning_amd.forget --gpus N ...), which owns the bucketed RCCL exchange.")
+                # transformers.Trainer wraps the model in torch DDP (mm/forget.py:161 ddp_find_unused_parameters), whose reducer
+                # listens on the parameter's AccumulateGrad node; a model that accumulates into a flat gradient buffer by hand
+                # and returns no gradient would never be reduced and the replicas would drift apart silently.  LlavaHIP can
+                # hand its gradient to autograd instead (one more parameter-sized tensor); anything else must say it is safe.
+                if hasattr(m, "enable_autograd_gradients"):
+                    m.enable_autograd_gradients()
+                else:
+                    raise RuntimeError(
+                        "hosted_by_hf_trainer() at WORLD_SIZE > 1: torch DDP cannot see this model's hand-written gradient "
+                        "accumulation.  Run data-parallel training through multimodal_unlearning_amd.engine.ForgetEngine "
+                        "(python -m multimodal_unlearning_amd.forget --gpus N ...), which owns the bucketed RCCL exchange.")
             transformers.Trainer.__init__(self, *args, **kwargs)
             # the reference's pinned transformers (4.45.1) divides every micro-batch loss by the accumulation steps;
             # 5.x skips that for models whose forward takes **kwargs unless this is False

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/mmu_hip.h but not exported"
     assert sorted(hip.SIGNATURES) == syms, set(hip.SIGNATURES) ^ set(syms)
-    assert lib.mmu_abi_version() == 3
+    assert lib.mmu_abi_version() == 4
 
 
 def test_header_arity_matches_binding():

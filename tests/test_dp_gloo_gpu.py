@@ -195,3 +195,87 @@ def test_forget_entry_point_merges_a_lora_run_on_two_ranks(tmp_path):
     assert (res[0] - merged).norm() / merged.norm() < 1e-6
     assert not os.path.exists(os.path.join(a, "adapter_config.json")) and os.path.exists(os.path.join(a, "adapter_config.json.merged"))
     assert not os.path.exists(os.path.join(a, ".merge_tmp"))
+
+
+def _hosted_worker(rank, world, port, q, loss, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      LOCAL_WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)  # transformers / accelerate adopt an existing group
+    try:
+        import transformers
+
+        from multimodal_unlearning_amd.config import tiny_test_config
+        from multimodal_unlearning_amd.llava import LlavaHIP
+        from multimodal_unlearning_amd.params import init_params
+        from multimodal_unlearning_amd.synthetic import teacher_params_from
+        from multimodal_unlearning_amd.trainer import MMTrainerForgetting, hosted_by_hf_trainer
+
+        cfg = tiny_test_config()
+        model = LlavaHIP(cfg, init_params(cfg, seed=0), device="cuda:0")
+        teacher = LlavaHIP(cfg, teacher_params_from(init_params(cfg, seed=0), seed=7), device="cuda:0", trainable=False)
+        data = [_batch(cfg, 60 + i, loss) for i in range(4)]      # every rank holds the list; accelerate deals the batches out
+        args = transformers.TrainingArguments(
+            output_dir=os.path.join(out_dir, f"r{rank}"), per_device_train_batch_size=1, gradient_accumulation_steps=1, max_steps=2,
+            learning_rate=1e-3, weight_decay=0.01, max_grad_norm=1e9, bf16=True, report_to=[], remove_unused_columns=False,
+            disable_tqdm=True, save_strategy="no", optim="adamw_torch", lr_scheduler_type="constant", warmup_steps=0,
+            ddp_backend="gloo", ddp_find_unused_parameters=True, dataloader_pin_memory=False)   # mm/forget.py:161
+
+        class InOrder(hosted_by_hf_trainer(MMTrainerForgetting)):
+            def _get_train_sampler(self, *a, **k):
+                return torch.utils.data.SequentialSampler(self.train_dataset)
+
+        tr = InOrder(model=model, args=args, train_dataset=data, data_collator=lambda x: x[0], forget_loss=loss,
+                     teacher_model=teacher, loss_beta=1.0, l1_lambda=0, l0_lambda=0, l_norm_from="zero", loss_args={})
+        assert model.autograd_grads and model.ddp_compatible
+        tr.train()
+        wrapped = type(tr.model_wrapped).__name__
+        torch.cuda.synchronize()
+        q.put((rank, wrapped, model.train_flat.detach().float().cpu().numpy()))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("loss", ["grad_diff_forget_ce_retain_ce", "kl"])
+def test_hosted_by_hf_trainer_under_torch_ddp_on_two_ranks(tmp_path, loss):
+    """The reference's arrangement at world 2: `class MMTrainerForgetting(Trainer)` (mm/trainer.py:112)
+    under transformers.Trainer, which wraps the model in torch DDP with find_unused_parameters=True (mm/forget.py:161).
+    LlavaHIP hands its flat gradient to autograd (`enable_autograd_gradients`), DDP's reducer averages it, HF's optimiser
+    (the fused flat AdamW) steps: replicas identical, and equal to ForgetEngine accumulating the same micro-batches."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_hosted_worker, args=(r, 2, port, q, loss, str(tmp_path))) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = [q.get(timeout=420) for _ in ps]
+    for p in ps:
+        p.join(120)
+        assert p.exitcode == 0
+    res = {r: torch.from_numpy(a) for r, _, a in got}
+    assert all(w == "DistributedDataParallel" for _, w, _ in got), [w for _, w, _ in got]
+    assert torch.equal(res[0], res[1])
+    from multimodal_unlearning_amd.config import ForgetConfig, tiny_test_config
+    from multimodal_unlearning_amd.engine import ForgetEngine
+    from multimodal_unlearning_amd.llava import LlavaHIP
+    from multimodal_unlearning_amd.params import init_params
+    from multimodal_unlearning_amd.synthetic import teacher_params_from
+    from multimodal_unlearning_amd.trainer import MMTrainerForgetting
+
+    cfg = tiny_test_config()
+    start = LlavaHIP(cfg, init_params(cfg, seed=0), device="cuda:0").train_flat.detach().float().cpu()
+    ref = LlavaHIP(cfg, init_params(cfg, seed=0), device="cuda:0")
+    teacher = LlavaHIP(cfg, teacher_params_from(init_params(cfg, seed=0), seed=7), device="cuda:0", trainable=False)
+    tr = MMTrainerForgetting(model=ref, forget_loss=loss, teacher_model=teacher, loss_beta=1.0, l1_lambda=0, l0_lambda=0,
+                             l_norm_from="zero", loss_args={})
+    eng = ForgetEngine(ref, tr, ForgetConfig(lr=1e-3, weight_decay=0.01, max_grad_norm=1e9), total_steps=10 ** 9, warmup_steps=0,
+                       transposed_weights=False, merge_ga=False)
+    data = [_batch(cfg, 60 + i, loss) for i in range(4)]
+    eng.step(data[0:2])   # rank 0 saw batch 0, rank 1 batch 1 (accelerate's BatchSamplerShard), DDP averaged
+    eng.step(data[2:4])
+    torch.cuda.synchronize()
+    want = ref.train_flat.detach().float().cpu()
+    moved = (want - start).norm()
+    err = (res[0] - want).norm()
+    assert moved > 1e-3 * start.norm() and err < 0.05 * moved, (float(err), float(moved))

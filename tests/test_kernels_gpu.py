@@ -1193,3 +1193,30 @@ def test_layernorm_bwd_params_vs_torch(dev):
         assert _relerr(dg, w.grad) < 4e-3 and _relerr(db, b.grad) < 4e-3, (M, d, _relerr(dg, w.grad), _relerr(db, b.grad))
         hip.layernorm_bwd_params(dy, x, dg, db, 1e-5, accumulate=True)
         assert _relerr(dg, 2 * w.grad) < 8e-3 and _relerr(db, 2 * b.grad) < 8e-3
+
+
+def test_dropout_kernel_mask_is_a_function_of_seed_and_index(dev):
+    """mmu_dropout_bf16 (peft's lora_dropout): kept fraction ~ 1 - p, kept values scaled by 1 / (1 - p), the same seed gives the
+    same mask (the backward pass regenerates it), another seed another mask, in place allowed, p = 0 is the identity."""
+    n = 1 << 20
+    x = torch.ones(n, device=dev, dtype=BF)
+    for p in (0.05, 0.1, 0.5):
+        a, b, c = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+        hip.dropout(x, a, p, 1234)
+        hip.dropout(x, b, p, 1234)
+        hip.dropout(x, c, p, 1235)
+        assert torch.equal(a, b) and not torch.equal(a, c)
+        kept = (a != 0).float().mean().item()
+        assert abs(kept - (1 - p)) < 4 * (p * (1 - p) / n) ** 0.5 + 1e-4, (p, kept)
+        assert torch.equal(a[a != 0], torch.full_like(a[a != 0], 1.0 / (1.0 - p)))
+        assert abs((a != 0).float().mean().item() - (c != 0).float().mean().item()) < 5e-3
+        both = ((a != 0) & (c != 0)).float().mean().item()                      # masks of two seeds are independent
+        assert abs(both - (1 - p) ** 2) < 5e-3
+    y = _randn((n,), dev, seed=3)
+    z = y.clone()
+    hip.dropout(z, z, 0.25, 99)
+    ref = torch.empty_like(y)
+    hip.dropout(y, ref, 0.25, 99)
+    assert torch.equal(z, ref)
+    hip.dropout(y, ref, 0.0, 5)
+    assert torch.equal(ref, y)

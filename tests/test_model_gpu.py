@@ -562,6 +562,128 @@ def test_keep_act_t_is_equivalent(dev):
     assert torch.equal(res[0][1], res[1][1])
 
 
+def test_lora_dropout_forward_and_backward_vs_autograd(dev):
+    """`LoRA.dropout` (mm/forget.py:128-136, config/mm/forget.yaml:6; peft: y = W x + (alpha/r) B A dropout(x)) on ONE adapted
+    Linear of the model against torch autograd of the same expression with the mask the kernel generates (read back by
+    running it on ones): output, dx, dA, dB.  peft is not importable and the mask stream is the library's own: parity unpinned
+    vs peft's RNG; the ARITHMETIC is pinned here."""
+    from multimodal_unlearning_amd import hip
+    from multimodal_unlearning_amd.llava import LlavaHIP, LoraSpec
+
+    cfg = tiny_test_config()
+    p_drop = 0.25
+    model = LlavaHIP(cfg, init_params(cfg, seed=0), device=dev, lora=LoraSpec(r=8, alpha=32.0, dropout=p_drop, seed=5))
+    model.init_lora_(seed=3, b_std=0.05)
+    model.ensure_grad().zero_()
+    wname = "text.layers.0.down.weight"
+    ad = model.lora[wname]
+    M, n_in, n_out = 96, ad.A32.shape[1], ad.BL.shape[0]
+    g = torch.Generator(device="cpu").manual_seed(0)
+    x = (torch.randn(M, n_in, generator=g)).to(dev).to(torch.bfloat16)
+    dy = (torch.randn(M, n_out, generator=g) * 0.1).to(dev).to(torch.bfloat16)
+    model._drop_seeds, model._fwd_U = {}, {}
+    out = torch.empty(M, n_out, device=dev, dtype=torch.bfloat16)
+    model._lin_fwd(wname, x, out)
+    seed = model._drop_seeds[wname]
+    mask = hip.dropout(torch.ones_like(x), torch.empty_like(x), p_drop, seed).float()     # 0 or 1 / (1 - p)
+    assert 0.6 < (mask != 0).float().mean().item() < 0.9
+    W = model.w[wname].float()
+    xr = x.float().requires_grad_(True)
+    A = ad.A32.detach().float().requires_grad_(True)
+    Bm = ad.BL.detach().float().requires_grad_(True)
+    s = model.lora_spec.scaling
+    ref = xr @ W.t() + s * ((xr * mask) @ A.t()) @ Bm.t()
+    assert _relerr(out, ref) < 6e-3
+    ref.backward(dy.float())
+    model._bwd_U = model._fwd_U
+    dx = torch.empty_like(x)
+    model._lin_bwd(wname, dy, x, dx)
+    base = wname[: -len(".weight")]
+    assert _relerr(dx, xr.grad) < 8e-3, _relerr(dx, xr.grad)
+    assert _relerr(model.g[base + ".lora_A"], A.grad) < 1e-2
+    assert _relerr(model.g[base + ".lora_B"], Bm.grad * ad.mask.float()) < 1e-2
+    model._drop_seeds = model._fwd_U = model._bwd_U = None
+
+
+def test_lora_dropout_in_the_step(dev):
+    """Dropout only acts in training forwards that build a graph; the loss moves with it, the engine trains, a recompute
+    (gradient checkpointing) regenerates the same masks, and eval() / no-grad forwards see no dropout."""
+    from multimodal_unlearning_amd.llava import LlavaHIP, LoraSpec
+    from multimodal_unlearning_amd.trainer import MMTrainerForgetting
+
+    cfg = tiny_test_config()
+    inputs = make_forget_batch(cfg, 2, 40, seed=43, n_question=7)
+
+    def build(p):
+        m = LlavaHIP(cfg, init_params(cfg, seed=0), device=dev, lora=LoraSpec(r=8, alpha=32.0, dropout=p, seed=11))
+        m.init_lora_(seed=3, b_std=0.05)
+        return m, MMTrainerForgetting(model=m, forget_loss="grad_ascent", teacher_model=None, loss_beta=1.0, l1_lambda=0,
+                                      l0_lambda=0, l_norm_from="init")
+
+    m0, t0 = build(0.0)
+    m1, t1 = build(0.3)
+    l0 = float(t0.compute_loss(m0, inputs))
+    l1 = t1.compute_loss(m1, inputs)
+    assert abs(float(l1) - l0) > 1e-4                                  # the adapters' input was masked
+    with torch.no_grad():
+        assert float(t1.compute_loss(m1, inputs)) == float(t0.compute_loss(m0, inputs)) == l0   # no graph: no dropout
+    m1.ensure_grad().zero_()
+    l1.backward()
+    g_plain = m1.ensure_grad().clone()
+    assert float(g_plain.float().norm()) > 0
+    # the same forward again draws NEW masks (another loss); a checkpointed one recomputes with the SAME masks it drew
+    m2, t2 = build(0.3)
+    m2.gradient_checkpointing_enable()
+    m2.ensure_grad().zero_()
+    l2 = t2.compute_loss(m2, inputs)
+    assert float(l2) == float(l1)                                      # same spec seed, same call order: same masks
+    l2.backward()
+    assert torch.equal(m2.ensure_grad(), g_plain)
+    m1.eval()
+    m1.ensure_grad().zero_()
+    le = t1.compute_loss(m1, inputs)
+    assert float(le) == l0
+    m1.train()
+
+
+@pytest.mark.parametrize("lora", [False, True])
+def test_gradient_checkpointing_is_equivalent(dev, lora):
+    """`model.gradient_checkpointing_enable()` (mm/forget.py:123-124): the forward keeps only each decoder layer's input, the
+    backward sweep re-runs the layer's forward with the same kernels — same loss and gradients bit for bit, full
+    fine-tuning (transposed-wgrad path, act^T kept or not) and LoRA, at a fraction of the saved bytes."""
+    from multimodal_unlearning_amd.llava import LlavaHIP, LoraSpec
+    from multimodal_unlearning_amd.trainer import MMTrainerForgetting
+
+    cfg = tiny_test_config(text_layers=4)
+    model = LlavaHIP(cfg, init_params(cfg, seed=0), device=dev, lora=LoraSpec(r=8, alpha=32.0) if lora else None)
+    if lora:
+        model.init_lora_(seed=3, b_std=0.02)
+    model.transposed_wgrad_min_m = 0
+    teacher = LlavaHIP(cfg, teacher_params_from(init_params(cfg, seed=0), seed=7), device=dev, trainable=False)
+    inputs = make_forget_batch(cfg, 2, 64, seed=33, n_question=9)
+    for loss_type in ("grad_diff_forget_ce_retain_ce", "KL"):
+        tr = MMTrainerForgetting(model=model, forget_loss=loss_type, teacher_model=teacher, loss_beta=1.0, l1_lambda=0,
+                                 l0_lambda=0, l_norm_from="init" if lora else "zero")
+        res = {}
+        for keep in (False, True):
+            for rc in (False, True):
+                model.keep_act_t = keep
+                (model.gradient_checkpointing_enable if rc else model.gradient_checkpointing_disable)()
+                model.ensure_grad().zero_()
+                torch.cuda.synchronize()
+                torch.cuda.reset_peak_memory_stats()
+                base = torch.cuda.memory_allocated()
+                loss = tr.compute_loss(model, inputs)
+                held = torch.cuda.memory_allocated() - base          # what the graph keeps alive between forward and backward
+                loss.backward()
+                torch.cuda.synchronize()
+                res[keep, rc] = (float(loss), model.ensure_grad().clone(), held)
+            assert res[keep, True][0] == res[keep, False][0], (loss_type, keep)
+            assert torch.equal(res[keep, True][1], res[keep, False][1]), (loss_type, keep)
+            assert res[keep, True][2] < 0.6 * res[keep, False][2], (loss_type, keep, res[keep, True][2], res[keep, False][2])
+    model.gradient_checkpointing_disable()
+
+
 def test_unfrozen_vision_tower_vs_oracle(dev):
     """`freeze_vision_module: false` (mm/forget.py:117-118, config/mm/forget.yaml:57): in full fine-tuning the CLIP tower trains
     with everything else.  Loss and EVERY gradient tensor — the tower's Linears and biases, LayerNorm gamma / beta, class and
