@@ -42,7 +42,7 @@ def _relerr(a, b):
     return ((a - b).norm() / (b.norm() + 1e-30)).item()
 
 
-def _oracle(cfg, P, Pt, loss_type, inputs):
+def _oracle(cfg, P, Pt, loss_type, inputs, padded_queries="eager"):
     """fp32 loss, logits of the LAST student forward (retain) and gradients of every trainable tensor."""
     from oracle.forget_losses_ref import compute_loss_ref
     from oracle.llava_ref import llava_forward
@@ -52,13 +52,13 @@ def _oracle(cfg, P, Pt, loss_type, inputs):
     last = {}
 
     def student(x):
-        out = llava_forward(cfg, Pf, **x)
+        out = llava_forward(cfg, Pf, **x, padded_queries=padded_queries)
         last["logits"], last["inputs"] = out["logits"].detach(), x
         if out["loss"] is not None:
             last["scale"] = last.get("scale", 0.0) + abs(float(out["loss"]))
         return out
 
-    teacher = (lambda x: llava_forward(cfg, Pt, **x)) if Pt is not None else None
+    teacher = (lambda x: llava_forward(cfg, Pt, **x, padded_queries=padded_queries)) if Pt is not None else None
     loss = compute_loss_ref(loss_type, student, teacher, inputs, 1.0)
     loss.backward()
     grads = {k: v.grad for k, v in Pf.items() if v.grad is not None}
@@ -290,25 +290,18 @@ def test_npo_full_width_vs_oracle(dev):
     Pt = teacher_params_from(P, seed=9)
     inputs = {"forget": make_split(cfg, B, S, seed=611, n_question=40, left_pad=[0, 21, 0]),
               "retain": make_split(cfg, B, S, seed=612, n_question=30)}
-    ref = _oracle(cfg, P, Pt, "npo", inputs)
+    # npo averages over every B*S row, padding included (mm/trainer.py:348-353 has no mask), so what the model computes at a
+    # padded QUERY position matters to this loss: the oracle runs with the reference's configured attention semantics there
+    # (flash_attention_2, mm/forget.py:86: zero output rows — which is also what the HIP kernels return), not eager's
+    # uniform average over masked keys
+    ref = _oracle(cfg, P, Pt, "npo", inputs, padded_queries="flash")
     valid = inputs["forget"]["attention_mask"].bool()
     for name, sw in CONFIGS[:2]:
         loss, logits, grads = _run_hip(dev, cfg, P, Pt, "npo", inputs, sw)
-        # the loss is ONE mean of ~2 ln 2 (not a difference of cross-entropies): bounded relative to itself, scale 0.
-        # Padded QUERY rows: npo averages over every B*S row, padding included (mm/trainer.py:348-353 has no mask), so what the
-        # model computes at a padded position matters to this loss.  There every key is masked: the oracle restates HF's eager
-        # attention (finfo.min fill -> a uniform average over all keys), the reference's configured flash_attention_2
-        # (mm/forget.py:86) returns zeros for those rows, and so do the HIP kernels.  The 21 padded positions all carry the
-        # pad id, so their (differently directed) gradients pile up in ONE embedding row: that row is left out of the
-        # comparison; every other tensor and row is held to the common bound.
-        pad_id = int(inputs["forget"]["input_ids"][1, 0])
-        assert int(inputs["forget"]["attention_mask"][1, 0]) == 0
-        w = _check(f"7b/{name}", (loss, logits[valid], grads), (ref[0], ref[1][valid], ref[2], ref[3], 0.0),
-                   skip_rows={"text.embed_tokens.weight": [pad_id]},
-                   # an embedding row's gradient is ONE token's hidden-state gradient (no averaging over tokens as in every
-                   # weight matrix), and npo's logit gradient is a difference of near-equal softmax terms spread over all
-                   # 32 064 entries: the bf16 rounding of dlogits shows in these rows first (measured 4.9e-2; KL: < 3e-2)
-                   bounds={"text.embed_tokens.weight": 7e-2})
+        # the loss is ONE mean of ~2 ln 2 (not a difference of cross-entropies): bounded relative to itself, scale 0.  (Against
+        # the EAGER oracle the same run is off by 4-5 % on norm weights and 100 % on the pad token's embedding row: the 21
+        # padded positions are where the two attention semantics differ, and this loss counts them.)
+        w = _check(f"7b/{name}", (loss, logits[valid], grads), (ref[0], ref[1][valid], ref[2], ref[3], 0.0))
         print(f"[fullwidth 7b npo {name}] loss {loss:+.6f} vs {ref[0]:+.6f}; logits {w[2]:.2e} (HF-bf16 {w[3]:.2e}); "
               f"worst grad {w[0]} {w[1]:.2e}")
 
