@@ -68,6 +68,10 @@ int mmu_gemm_set_group_m(int group_m);
  * order in every round (shared A panels: one HBM read + Infinity-Cache hits), 0 = one contiguous chunk of the order per XCD
  * (rounds 1-2; A/B). */
 int mmu_gemm_set_xcd_map(int mode);
+/* 256x256 kernel, experiment switch: workgroups of XCD x (blockIdx.x & 7) start x * units * ~1 us late, so that the eight
+ * XCDs' epilogue stores do not hit HBM at the same moment (each XCD's 32 CUs stay in lockstep: they share panels in L2).
+ * 0 (default) = off. */
+int mmu_gemm_set_xcd_skew(int units);
 /* 256x256 kernel launch mode.  1 (default) = persistent: one workgroup per compute unit draws tiles from a device-side
  * queue, so a workgroup whose CU is held by another kernel (RCCL's all-reduce during the overlapped gradient exchange of
  * mm/forget.py:23-31's DDP counterpart) takes fewer tiles instead of delaying a fixed share; needs

@@ -33,6 +33,7 @@ static int g_persist = 1;     // mmu_gemm_set_persistent: 0 one workgroup per ti
 static int* g_tileq = nullptr;   // mmu_gemm_set_tile_queue: TQ_SLOTS x 16 zeroed ints (8 per-XCD-class tile counters + 1 exit counter per slot)
 static std::atomic<unsigned> g_tileq_seq{0};  // launches take the slots round-robin (also from several host threads), so kernels in flight on different streams never share one
 static int g_num_cu = 256;    // MI355X; replaced by the device's own count on the first launch (cu_count())
+static int g_xcd_skew = 0;       // mmu_gemm_set_xcd_skew: start delay per XCD index, in units of s_sleep(32) (~1 us); experiment
 static int g_tail_split = 1;     // mmu_gemm_set_tail_split: 0 off, 1 heuristic, 2 whenever the remainder is <= half a round
 static float* g_sk_ws = nullptr;  // mmu_gemm_set_workspace
 static size_t g_sk_ws_bytes = 0;
@@ -85,6 +86,7 @@ struct GemmArgs {
     //     halves hold g and u of the SAME hidden unit —, C2 = act = bf16(silu(g)) * u [M][gu_I], CT = act^T [gu_I][ldct]
     //  5: the GEMM's output dact [M][gu_I] is never stored: with g, u read from `gu` the epilogue writes C = dgu [M][2 gu_I]
     //     and CT = dgu^T [2 gu_I][ldct]
+    int xcd_skew;  // 256^2 kernel: workgroups of XCD x (blockIdx.x & 7) start x * xcd_skew * ~1 us late (0 = off)
     int epi_mode, gu_I;
     bf16* C2;
     int ldc2;
@@ -544,6 +546,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     const unsigned long long stamp_t0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
 
+    // XCD start skew (experiment, mmu_gemm_set_xcd_skew): all workgroups run tiles of the same duration in lockstep, so their
+    // epilogue stores hit HBM together and the matrix pipes idle meanwhile.  The 32 CUs of an XCD must stay in K-lockstep
+    // (they share panels through their L2), but the 8 XCDs need not: XCD x starts x * skew late.
+    if (p.xcd_skew) {
+        const int nsl = (int)(blockIdx.x & 7) * p.xcd_skew;
+        for (int i = 0; i < nsl; ++i) __builtin_amdgcn_s_sleep(32);
+    }
     const int total_tiles = p.tiles_m * p.tiles_n;
     const int nk = (p.K + 63) / 64;
     // Work of this workgroup: whole tiles (vt, then vt + grid in the persistent launch), or — split-K worker — one K
@@ -1026,6 +1035,7 @@ int launch_epi(GemmArgs a, hipStream_t stream) {
     a.tiles_n = (a.N + 255) / 256;
     a.group_m = g_group_m > 0 ? g_group_m : 4;
     a.xcd_map = g_xcd_map;
+    a.xcd_skew = g_xcd_skew;
     const int tiles = a.tiles_m * a.tiles_n;
     // Split-K tail: with T tiles on 256 CUs the last T % 256 tiles occupy a whole round; when they are at most half a
     // round, cut each into S = 256 / rem K ranges over rem * S extra workgroups (gate_up wgrad: 96 tiles x 2 ranges
@@ -1250,6 +1260,11 @@ extern "C" int mmu_fold_f32_into_bf16(float* src32, void* dst, const void* mask,
 extern "C" int mmu_gemm_set_xcd_map(int mode) {
     if (mode < 0 || mode > 1) return -1;
     g_xcd_map = mode;
+    return 0;
+}
+extern "C" int mmu_gemm_set_xcd_skew(int units) {
+    if (units < 0 || units > 64) return -1;
+    g_xcd_skew = units;
     return 0;
 }
 extern "C" int mmu_gemm_set_persistent(int mode) {

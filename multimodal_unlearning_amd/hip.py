@@ -34,6 +34,7 @@ SIGNATURES = {
     "mmu_gemm_set_xcd_map": [_i],
     "mmu_gemm_set_tail_split": [_i],
     "mmu_gemm_set_workspace": [_vp, _ll],
+    "mmu_gemm_set_xcd_skew": [_i],
     "mmu_gemm_set_tile_queue": [_vp, _ll],
     "mmu_gemm_reset_tile_queue": [],
     "mmu_attn_fwd": [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp],
@@ -294,6 +295,10 @@ def gemm_tile_queue_bytes() -> int:
     lib.mmu_gemm_tile_queue_bytes.restype = C.c_longlong
     lib.mmu_gemm_tile_queue_bytes.argtypes = []
     return int(lib.mmu_gemm_tile_queue_bytes())
+
+
+def gemm_set_xcd_skew(units: int):
+    _check(load().mmu_gemm_set_xcd_skew(int(units)), "mmu_gemm_set_xcd_skew")
 
 
 def gemm_set_tile(tile: int):

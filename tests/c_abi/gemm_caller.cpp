@@ -32,7 +32,7 @@ static float bf2f(uint16_t h) {
     } while (0)
 
 int main() {
-    if (mmu_abi_version() != 3) return 3;
+    if (mmu_abi_version() < 3) return 3;  // the entry points used here exist since version 3; later versions only add
     const int M = 520, N = 264, K = 392;  // ragged against every tile size
     std::vector<uint16_t> A((size_t)M * K), B((size_t)N * K), C((size_t)M * N), C0((size_t)M * N);
     uint32_t s = 12345u;
