@@ -1039,7 +1039,8 @@ def test_forget_entry_point_text_modality(dev, tmp_path):
 
 def test_forget_entry_point_lora_gating_follows_the_reference(dev, tmp_path):
     """mm/forget.py:126: `LoRA.r != 0 and (l_norm_from != "zero" or l1_lambda == 0)` — with an L1 penalty on the distance
-    from zero the reference silently runs FULL fine-tuning although LoRA.r is set; LoRA.dropout != 0 is refused."""
+    from zero the reference silently runs FULL fine-tuning although LoRA.r is set; LoRA.dropout (:128-136) reaches the
+    adapters (round 4; it was refused before) and is written to adapter_config.json."""
     from multimodal_unlearning_amd.forget import ForgetRunConfig, parse_overrides, run
 
     base = ["model_family=tiny", "forget_data_path=synthetic:4", "batch_size=2", "gradient_accumulation_steps=1",
@@ -1048,8 +1049,13 @@ def test_forget_entry_point_lora_gating_follows_the_reference(dev, tmp_path):
     assert not eng.model.lora and eng.model.train_flat.numel() > 100000          # full fine-tuning
     eng = run(parse_overrides(base + [f"save_dir={tmp_path / 'b'}", "l1_lambda=1e-4", "l_norm_from=init"], ForgetRunConfig()))
     assert eng.model.lora                                                        # adapters (distance from init)
-    with pytest.raises(SystemExit):
-        run(parse_overrides(base + [f"save_dir={tmp_path / 'c'}", "LoRA.dropout=0.05"], ForgetRunConfig()))
+    base[-1] = "save_model=true"
+    eng = run(parse_overrides(base + [f"save_dir={tmp_path / 'c'}", "LoRA.dropout=0.05"], ForgetRunConfig()))
+    assert eng.model.lora and eng.model.lora_spec.dropout == 0.05
+    import json
+    assert json.load(open(os.path.join(tmp_path / "c", "adapter_config.json")))["lora_dropout"] == 0.05
+    with pytest.raises(ValueError):
+        run(parse_overrides(base + [f"save_dir={tmp_path / 'd'}", "LoRA.dropout=1.0"], ForgetRunConfig()))
 
 
 def test_l1_regulariser_with_lora_follows_the_reference(dev):
