@@ -562,6 +562,20 @@ def test_keep_act_t_is_equivalent(dev):
     assert torch.equal(res[0][1], res[1][1])
 
 
+def test_second_backward_through_a_loss_only_forward_raises(models):
+    """the CE gradient of a loss-only forward overwrites the compact logits in place through the C ABI (invisible to
+    autograd's version counters): a second backward through the same graph must fail loudly, not differentiate garbage."""
+    cfg, P, student, _ = models
+    sp = make_forget_batch(cfg, 2, 40, seed=47, n_question=7)["forget"]
+    student.ensure_grad().zero_()
+    loss = student(**sp, loss_only=True).loss
+    loss.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="twice"):
+        loss.backward()
+    student.ensure_grad().zero_()
+    student.live_sweeps = 0
+
+
 def test_lora_dropout_forward_and_backward_vs_autograd(dev):
     """`LoRA.dropout` (mm/forget.py:128-136, config/mm/forget.yaml:6; peft: y = W x + (alpha/r) B A dropout(x)) on ONE adapted
     Linear of the model against torch autograd of the same expression with the mask the kernel generates (read back by
