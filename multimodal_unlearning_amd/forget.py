@@ -380,7 +380,7 @@ def run(rc: ForgetRunConfig):
     if rc.save_model and rank == 0:
         if lora is not None:
             save_pretrained(cfg, model.w, rc.save_dir, extra=extra, lora_state=model.lora_state(), lora_r=rc.lora_r,
-                            lora_alpha=rc.lora_alpha)
+                            lora_alpha=rc.lora_alpha, lora_dropout=rc.lora_dropout)
         else:
             save_pretrained(cfg, model.w, rc.save_dir, extra=extra)
         log("saved", rc.save_dir)
