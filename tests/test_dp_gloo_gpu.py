@@ -279,3 +279,48 @@ def test_hosted_by_hf_trainer_under_torch_ddp_on_two_ranks(tmp_path, loss):
     moved = (want - start).norm()
     err = (res[0] - want).norm()
     assert moved > 1e-3 * start.norm() and err < 0.05 * moved, (float(err), float(moved))
+
+
+def _merged_worker(rank, world, port, q, loss):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cfg, model, eng = _build("cuda:0", False, loss, None, "allreduce")
+        groups = []
+        for step in range(2):
+            eng.step([_batch(cfg, 70 + 10 * step + 2 * rank + i, loss) for i in range(2)])   # GA 2 per rank
+            groups.append(list(eng.last_groups))
+        torch.cuda.synchronize()
+        q.put((rank, groups, model.train_flat.detach().float().cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("loss", ["grad_diff_forget_ce_retain_ce", "kl"])
+def test_ranks_with_merged_micro_batches_match_gradient_accumulation(loss):
+    """Round 4: each rank evaluates its two gradient-accumulation micro-batches as ONE merged forward/backward
+    (ForgetEngine._groups) — the bucket hooks then fire from that single sweep —; replicas identical, and equal to one
+    process that walks all four micro-batches one by one."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_merged_worker, args=(r, 2, port, q, loss)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = [q.get(timeout=300) for _ in ps]
+    for p in ps:
+        p.join(120)
+        assert p.exitcode == 0
+    res = {r: torch.from_numpy(a) for r, _, a in got}
+    assert all(g == [[2], [2]] for _, g, _ in got), [g for _, g, _ in got]
+    assert torch.equal(res[0], res[1])
+    cfg, model, eng = _build("cuda:0", False, loss, None)
+    eng.merge_ga = False
+    for step in range(2):
+        eng.step([_batch(cfg, 70 + 10 * step + 2 * r + i, loss) for r in range(2) for i in range(2)])
+    torch.cuda.synchronize()
+    ref = model.train_flat.detach().float().cpu()
+    moved = (ref - _build("cuda:0", False, loss, None)[1].train_flat.detach().float().cpu()).norm() / ref.norm()
+    err = (res[0] - ref).norm() / ref.norm()
+    assert moved > 1e-3 and err < 0.06 * moved, (float(err), float(moved))
