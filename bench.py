@@ -152,6 +152,14 @@ class GemmTimer:
             b[0] += 1
             b[1] += f
             b[2] += ms * 1e-3
+        # the same sum over the launches with a plain GEMM epilogue only (store / bias+residual / accumulate): the launches
+        # that carry the SwiGLU forward / backward in their epilogue move 2-3x the bytes per FLOP and are listed by shape
+        self.plain = [0.0, 0.0, 0]
+        for layout, m, n, k, e0, e1, acc, res in self.records:
+            if not isinstance(res, str):
+                self.plain[0] += 2.0 * m * n * k
+                self.plain[1] += e0.elapsed_time(e1) * 1e-3
+                self.plain[2] += 1
         # the step's GEMM shapes, heaviest first: where the kernel's time goes and what each shape reaches
         shp = {}
         for layout, m, n, k, e0, e1, acc, res in self.records:
@@ -681,6 +689,11 @@ def main():
                          "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(timer.alg_bytes / n),
                          "kernel": "g256::gemm256_kernel / gemm_bf16_kernel (all layouts)",
                          "launches": n, "avg_launch_us": round(t / n * 1e6, 1),
+                         # (launches with a plain store / bias+residual / accumulate epilogue alone — the figure rounds 1-3
+                         # reported, before SwiGLU moved into two GEMM epilogues per layer)
+                         "plain_epilogue_launches": {"launches": timer.plain[2],
+                                                     "achieved": round(timer.plain[0] / max(timer.plain[1], 1e-12) / 1e12, 1),
+                                                     "frac": round(timer.plain[0] / max(timer.plain[1], 1e-12) / PEAK_BF16, 4)},
                          "gemm_share_of_step": round(t / (elapsed / args.steps), 3), "by_layout": by,
                          "by_shape": timer.by_shape,
                          # the other kernels of the same (last timed) step, event-timed in place: attention forward / dQ /
