@@ -231,6 +231,9 @@ class ForgetEngine:
         from . import hip  # HIP optimiser kernels; fails loudly when the library is missing
 
         self.hip = hip
+        if getattr(model, "autograd_grads", False):
+            raise ValueError("ForgetEngine owns the flat gradient buffer itself: the model is in autograd-gradient mode "
+                             "(LlavaHIP.enable_autograd_gradients, for torch DDP under transformers.Trainer)")
         self.model, self.trainer, self.cfg = model, trainer, cfg
         self.total_steps, self.warmup_steps = total_steps, warmup_steps
         self.group = group
