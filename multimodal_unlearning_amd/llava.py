@@ -58,7 +58,7 @@ class LoraSpec:
 
 class _Adapter:
     """One (possibly fused) LoRA module: y = x W^T + s * (x A^T) B^T.  A32 [kl,in] and BL [out,kl] are views of the
-    trainable flat buffer (kl = 32 or 64 >= k*r, zero padded; fused q|k|v / gate|up adapters are block-diagonal in
+    trainable flat buffer (kl = k*r rounded up to 32, zero padded; fused q|k|v / gate|up adapters are block-diagonal in
     BL, enforced by `mask`).  Derived, refreshed after every optimiser step: A32s = s*A32, A32T = A32^T, BLs = s*BL."""
     __slots__ = ("name", "k", "r", "kl", "A32", "BL", "gA", "gB", "mask", "A32s", "A32T", "BLs")
 
@@ -373,9 +373,9 @@ class LlavaHIP(nn.Module):
         plan = []
         for wname, k in self._lora_targets(spec):
             n_out, n_in = self._specs[wname]
-            kl = 32 if k * spec.r <= 32 else 64
-            if k * spec.r > 64:
-                raise ValueError("fused LoRA rank k*r > 64 is not supported by the GEMM epilogue")
+            # padded inner width of the (possibly fused) adapter: 32 or 64 ride in the GEMM epilogue; wider ones (e.g. r = 32
+            # on the fused q|k|v: 96) are applied as a second, accumulating GEMM — which is also how peft adds its branch
+            kl = (k * spec.r + 31) // 32 * 32
             base = wname[: -len(".weight")]
             self._toff[base + ".lora_A"] = (off, (kl, n_in))
             off += kl * n_in
@@ -519,6 +519,9 @@ class LlavaHIP(nn.Module):
         hip.gemm(hip.NT, self._adapter_input(wname, x), ad.A32s, U)  # s * drop(x) A^T
         if self._fwd_U is not None:
             self._fwd_U[wname] = U  # [M,32]: kept for the adapter wgrad dB = s dy^T (x A^T) instead of re-reading x
+        if ad.kl > 64:  # wider than the fused epilogue takes: base GEMM, then out += U B^T
+            hip.gemm(hip.NT, x, self.w[wname], out, bias=bias, resid=resid)
+            return hip.gemm(hip.NT, U, ad.BL, out, accumulate=True)
         return hip.gemm(hip.NT, x, self.w[wname], out, bias=bias, resid=resid, lora_u=U, lora_b=ad.BL)
 
     def _qkv_fwd(self, wname, x, qkv, pos, H, D, dt):
@@ -531,10 +534,15 @@ class LlavaHIP(nn.Module):
             hip.gemm(hip.NT, self._adapter_input(wname, x), ad.A32s, U)
             if self._fwd_U is not None:
                 self._fwd_U[wname] = U
-        if D == 128 and self.fuse_rope and hip.gemm_rope(x, self.w[wname], qkv, pos, self._cos, self._sin, 2 * dt, lora_u=U,
-                                      lora_b=None if ad is None else ad.BL):
+        wide = ad is not None and ad.kl > 64   # adapter too wide for the fused epilogue: added by a second GEMM, RoPE after it
+        if D == 128 and self.fuse_rope and not wide and hip.gemm_rope(x, self.w[wname], qkv, pos, self._cos, self._sin, 2 * dt,
+                                                                    lora_u=U, lora_b=None if ad is None else ad.BL):
             return
-        hip.gemm(hip.NT, x, self.w[wname], qkv, lora_u=U, lora_b=None if ad is None else ad.BL)
+        if wide:
+            hip.gemm(hip.NT, x, self.w[wname], qkv)
+            hip.gemm(hip.NT, U, ad.BL, qkv, accumulate=True)
+        else:
+            hip.gemm(hip.NT, x, self.w[wname], qkv, lora_u=U, lora_b=None if ad is None else ad.BL)
         hip.rope(qkv, pos, self._cos, self._sin, H, H, D, dt)
 
     def _lora_scratch(self, n):
@@ -557,7 +565,10 @@ class LlavaHIP(nn.Module):
         seed = self._drop_seeds.get(wname) if self._drop_seeds is not None else None
         if dx is not None:
             wT = wname in self.wT
-            if seed is None:   # the adapter's term s dy B A rides in the dgrad GEMM's epilogue
+            if seed is None and ad.kl > 64:  # wide adapter: dx = dy W, then dx += (s dy B) A
+                hip.gemm(hip.NT if wT else hip.NN, dy, self.wT[wname] if wT else self.w[wname], dx)
+                hip.gemm(hip.NT, Vs, ad.A32T, dx, accumulate=True)
+            elif seed is None:   # the adapter's term s dy B A rides in the dgrad GEMM's epilogue
                 hip.gemm(hip.NT if wT else hip.NN, dy, self.wT[wname] if wT else self.w[wname], dx, lora_u=Vs, lora_b=ad.A32T)
             else:              # lora_dropout: that term passes the forward's mask first, so it is formed on its own
                 hip.gemm(hip.NT if wT else hip.NN, dy, self.wT[wname] if wT else self.w[wname], dx)

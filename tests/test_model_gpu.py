@@ -562,6 +562,46 @@ def test_keep_act_t_is_equivalent(dev):
     assert torch.equal(res[0][1], res[1][1])
 
 
+def test_lora_rank_wider_than_the_fused_epilogue_vs_oracle(dev):
+    """LoRA r = 32 (fused q|k|v adapter: 3 x 32 = 96 > the 64 columns the GEMM epilogue can carry): the adapter branch is then a
+    second, accumulating GEMM (forward and dgrad), RoPE runs after it; loss and adapter gradients vs the fp32 oracle on
+    W + (alpha/r) B A as for the fused ranks."""
+    from multimodal_unlearning_amd.llava import LlavaHIP, LoraSpec
+    from multimodal_unlearning_amd.trainer import MMTrainerForgetting
+    from oracle.llava_ref import llava_forward
+
+    cfg = tiny_test_config()
+    P = init_params(cfg, seed=0)
+    spec = LoraSpec(r=32, alpha=64.0)
+    model = LlavaHIP(cfg, P, device=dev, lora=spec)
+    model.init_lora_(seed=3, b_std=0.02)
+    assert model.lora["text.layers.0.qkv.weight"].kl == 96 and model.lora["text.layers.0.gate_up.weight"].kl == 64
+    inputs = make_forget_batch(cfg, 2, 40, seed=23, n_question=7)
+    tr = MMTrainerForgetting(model=model, forget_loss="grad_ascent", teacher_model=None, loss_beta=1.0, l1_lambda=0,
+                             l0_lambda=0, l_norm_from="init")
+    model.ensure_grad().zero_()
+    loss = tr.compute_loss(model, inputs)
+    loss.backward()
+    torch.cuda.synchronize()
+    leaves = {}
+    Pe = {k: v.clone() for k, v in P.items()}
+    for wname, ad in model.lora.items():
+        A = ad.A32.detach().float().cpu().requires_grad_(True)
+        Bm = ad.BL.detach().float().cpu().requires_grad_(True)
+        leaves[wname] = (A, Bm, ad.mask.float().cpu())
+        Pe[wname] = P[wname] + spec.scaling * ((Bm * ad.mask.float().cpu()) @ A)
+    ref = -llava_forward(cfg, Pe, **inputs["forget"])["loss"]
+    ref.backward()
+    assert abs(loss.item() - ref.item()) < 1e-3 * max(1.0, abs(ref.item())), (loss.item(), ref.item())
+    num = den = 0.0
+    for wname, (A, Bm, mask) in leaves.items():
+        base = wname[: -len(".weight")]
+        for got, exp in ((model.g[base + ".lora_A"].float().cpu(), A.grad), (model.g[base + ".lora_B"].float().cpu(), Bm.grad * mask)):
+            num += float((got - exp).pow(2).sum())
+            den += float(exp.pow(2).sum())
+    assert (num / den) ** 0.5 < 3e-2, (num / den) ** 0.5
+
+
 def test_second_backward_through_a_loss_only_forward_raises(models):
     """the CE gradient of a loss-only forward overwrites the compact logits in place through the C ABI (invisible to
     autograd's version counters): a second backward through the same graph must fail loudly, not differentiate garbage."""
