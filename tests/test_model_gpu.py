@@ -943,6 +943,7 @@ def test_engine_trajectory_vs_hf_trainer_golden(dev):
     ref_prev = None
     for k in range(steps):
         st = eng.step(mbs[k * ga:(k + 1) * ga], sync_loss=True)
+        assert eng.last_groups == [ga]   # round 4: the GA micro-batches of an update run as ONE merged forward/backward
         gn = float(eng.sumsq[0].sqrt())  # norm of the accumulated (already / GA) gradient, before clipping
         pn = model.train_flat.detach().float().norm().item()
         assert st.lr == pytest.approx(float(g["lr"][k]), rel=1e-6, abs=1e-12), (k, st.lr)
