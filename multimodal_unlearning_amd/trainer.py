@@ -382,7 +382,28 @@ class MMTrainerForgetting:
             image_token_index = _inner(model).config.image_token_index
             idk_logits = tu.remove_image_tokens(idk_inputs["input_ids"], idk_outputs.logits, image_token_index)
             idk_loss_current = -1 * tu.get_batch_loss(idk_logits, idk_inputs["labels"])
-            loss = -idk_loss_current.mean()
+            variant = self.loss_args.get("dpo_variant", "reference")
+            if variant == "reference":      # the LAST of the three assignments at mm/trainer.py:394-396 is what the reference trains on
+                loss = -idk_loss_current.mean()
+            elif variant in ("logsigmoid", "pi_logratios"):
+                # The two values the reference computes and overwrites (:390-395), offered behind a flag:
+                # "logsigmoid" = DPO proper, -logsigmoid(0.1 * (pi_logratios - ref_logratios)).mean() with the frozen
+                # teacher as reference policy; "pi_logratios" = -(log p(idk) - log p(forget)).mean().  Per-sequence
+                # log-likelihoods are `get_batch_loss` sums (HIP CE kernels); the [B]-vector arithmetic on top is host glue.
+                def seq_logp(m, split, grad):
+                    with torch.enable_grad() if grad else torch.no_grad():
+                        lg = tu.remove_image_tokens(split["input_ids"], m(**{k: v for k, v in split.items() if k != "labels"}).logits,
+                                                    image_token_index)
+                        return -1 * tu.get_batch_loss(lg, split["labels"])
+                forget_loss_current = seq_logp(model, forget_inputs, True)
+                pi_logratios = idk_loss_current - forget_loss_current
+                if variant == "pi_logratios":
+                    loss = -pi_logratios.mean()
+                else:
+                    ref_logratios = seq_logp(self.teacher_model, idk_inputs, False) - seq_logp(self.teacher_model, forget_inputs, False)
+                    loss = -torch.nn.functional.logsigmoid(0.1 * (pi_logratios - ref_logratios)).mean()   # beta = 0.1 (:393)
+            else:
+                raise ValueError(f"Invalid dpo_variant {variant!r}: expected 'reference', 'logsigmoid' or 'pi_logratios'")
 
         elif lt == "sku":
             bad_loss = self._loss_of(model, forget_inputs).loss
