@@ -448,6 +448,9 @@ def main():
     ap.add_argument("--recompute", action="store_true",
                     help="gradient checkpointing (mm/forget.py:123-124): keep one tensor per decoder layer, re-run the layer's "
                          "forward in backward (+1/3 FLOPs, executed and priced)")
+    ap.add_argument("--no-overlap-optimizer", action="store_true",
+                    help="A/B: AdamW + W^T refresh on the main stream after the step (round-3 behaviour); default: on a side "
+                         "stream, chunk by chunk in forward order, under the next step's forward (bit-identical results)")
     ap.add_argument("--no-merge-ga", action="store_true",
                     help="A/B: walk the gradient-accumulation micro-batches one by one (round-3 behaviour); default: micro-batches "
                          "that fit HBM together run as ONE concatenated forward/backward (ForgetEngine._groups)")
@@ -513,7 +516,7 @@ def main():
     fcfg = ForgetConfig(batch_size=args.micro_batch, gradient_accumulation_steps=args.grad_accum)
     eng = ForgetEngine(model, tr, fcfg, total_steps=args.steps + args.warmup + 1, warmup_steps=1,
                        transposed_weights=not args.no_wt, optimizer=args.optim, dp_mode=args.dp_mode,
-                       merge_ga=not args.no_merge_ga)
+                       merge_ga=not args.no_merge_ga, overlap_optimizer=not args.no_overlap_optimizer)
 
     if args.squat_workgroups:
         import ctypes
@@ -662,7 +665,7 @@ def main():
                                     f"{'LoRA r=%d' % args.lora_r if args.lora_r else 'full-FT'}, tuple inputs [B,{S}] right-padded, random-init weights"),
                        "micro_batch_pairs_per_gpu": B,
                        "grad_accum": GA, "global_batch": world * B * GA, "seq_len": S, "parallelism": f"dp{world}",
-                       "paired_fusion": not args.no_fuse,
+                       "paired_fusion": not args.no_fuse, "overlap_optimizer": bool(eng.overlap_optimizer),
                        # micro-batches evaluated per forward/backward: [1, 1, 1, 1] = the loop, [4] = one merged sweep
                        "ga_groups": headline_groups,
                        "optimizer": ("AdamW fp32 moments" if args.optim == "adamw" else "AdamW block-wise 8-bit moments") + ", clip 1.0",

@@ -227,7 +227,7 @@ class ForgetEngine:
     def __init__(self, model, trainer, cfg: ForgetConfig, total_steps: int = 1000, warmup_steps: int = 0,
                  group=None, transposed_weights: bool = True, force_collectives: bool = False,
                  optimizer: str = "adamw", dp_mode: str = "allreduce", bucket_elems: int = 1 << 27,
-                 merge_ga: bool = True, merge_tokens="auto"):
+                 merge_ga: bool = True, merge_tokens="auto", overlap_optimizer: bool = False):
         from . import hip  # HIP optimiser kernels; fails loudly when the library is missing
 
         self.hip = hip
@@ -285,6 +285,17 @@ class ForgetEngine:
         # gradient-accumulation micro-batches are evaluated as one concatenated batch where shapes, loss and HBM allow
         # (`_groups`); merge_tokens: "auto" = from free HBM, or an explicit cap on positions per forward
         self.merge_ga, self.merge_tokens, self.last_groups = merge_ga, merge_tokens, []
+        # overlap_optimizer: AdamW and the W^T refresh of a step run on a side stream, one chunk of the flat buffer per
+        # decoder layer in forward order, while the NEXT step's forward already runs on the main stream; the model waits for
+        # a chunk's event right before it first reads that chunk (LlavaHIP._wait_params).  Same kernels, same arithmetic, same
+        # order per element: results are bit-identical to the serial step.  What the caller must know: after step() returns,
+        # the parameters are only guaranteed complete for the model's own forwards — anything else that reads them on the
+        # main stream (a checkpoint, a test) calls finish_optimizer() first.  Full fine-tuning with fp32 moments and the
+        # all-reduce mode only (everything else keeps the serial step).
+        self.overlap_optimizer = bool(overlap_optimizer) and self.grad.is_cuda and optimizer == "adamw" and self.whole \
+            and not getattr(model, "lora", None) and hasattr(model, "param_chunks")
+        self._side = torch.cuda.Stream(device=dev) if self.overlap_optimizer else None
+        self._chunks = None
         # exposed gradient-exchange time: the stretch of the compute stream between the end of the last backward sweep
         # and the completion of the last collective (device events; read by bench.py, never synchronised here)
         self.time_exchange = False
@@ -370,6 +381,47 @@ class ForgetEngine:
             i = j
         return out
 
+    def _pipelined_adamw(self, lr):
+        """AdamW + W^T refresh chunk by chunk on the side stream (see overlap_optimizer in __init__)."""
+        model, c = self.model, self.cfg
+        p = model.train_flat.data
+        if self._chunks is None:
+            from .params import no_weight_decay
+            nd_abs = sorted(model.range_of(n) for n in model.trainable_names() if no_weight_decay(n))
+            self._chunks = []
+            for key, lo, hi in model.param_chunks():
+                rel = [(max(a, lo) - lo, min(b, hi) - lo) for a, b in nd_abs if a < hi and lo < b]
+                nd = torch.tensor(rel, device=p.device, dtype=torch.int64).reshape(-1, 2) if rel else None
+                prefix = f"text.layers.{key}." if isinstance(key, int) else None
+                self._chunks.append((key, lo, hi, nd, prefix))
+        main = torch.cuda.current_stream()
+        self._side.wait_stream(main)          # the gradients are final and |g|^2 is in self.sumsq
+        events = {}
+        with torch.cuda.stream(self._side):
+            for key, lo, hi, nd, prefix in self._chunks:
+                self.hip.adamw(p[lo:hi], self.grad[lo:hi], self.m[lo:hi], self.v[lo:hi], lr, c.adam_beta1, c.adam_beta2,
+                               c.adam_eps, c.weight_decay, self.opt_step, self.sumsq, c.max_grad_norm, 1.0 / self.world, True,
+                               nodecay=nd)
+                if model.wT:
+                    if prefix is not None:
+                        model.refresh_transposed_weights(prefix)
+                    elif key == "post":
+                        model.refresh_transposed_weights("lm_head.")
+                    else:
+                        for pre in ("projector.", "vision."):
+                            model.refresh_transposed_weights(pre)
+                ev = torch.cuda.Event()
+                ev.record(self._side)
+                events[key] = ev
+        model.param_events = events
+        model._derived_at = model.train_flat._version
+
+    def finish_optimizer(self):
+        """Make the main stream wait for the (possibly still running) parameter update of the last step: call before anything
+        but the model's own forward reads the parameters (checkpointing, comparisons).  No-op for the serial step."""
+        if self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
+
     def step(self, micro_batches: List[Dict], sync_loss: bool = False) -> StepStats:
         ga = len(micro_batches)
         model = self.model
@@ -405,7 +457,9 @@ class ForgetEngine:
         self._grad_sumsq()
         c, p = self.cfg, model.train_flat.data
         whole = self.whole
-        if self.optimizer == "adamw":
+        if self.overlap_optimizer:
+            self._pipelined_adamw(lr)
+        elif self.optimizer == "adamw":
             for (lo, hi), off, nd in zip(self.shards, self.shard_off, self.nodecay):
                 self.hip.adamw(p[lo:hi], self.grad[lo:hi], self.m[off:off + hi - lo], self.v[off:off + hi - lo], lr,
                                c.adam_beta1, c.adam_beta2, c.adam_eps, c.weight_decay, self.opt_step, self.sumsq,
@@ -417,7 +471,8 @@ class ForgetEngine:
         if not whole:
             self.grad.zero_()  # the other ranks' shards still hold this rank's unreduced partial sums
             self.reducer.gather_params(p)
-        model.refresh_derived()  # W^T copies (full fine-tuning) or LoRA's scaled / transposed adapter copies
+        if not self.overlap_optimizer:
+            model.refresh_derived()  # W^T copies (full fine-tuning) or LoRA's scaled / transposed adapter copies
         mean_loss = (total / ga)
         if sync_loss:
             if self.world > 1:

@@ -342,8 +342,10 @@ def run(rc: ForgetRunConfig):
         trainer = MMTrainerForgetting(model=model, teacher_model=teacher, forget_loss=lt, loss_beta=rc.loss_beta,
                                       l1_lambda=rc.l1_lambda, l0_lambda=rc.l0_lambda, l_norm_from=rc.l_norm_from,
                                       loss_args={"bad_weight": 2.5, "random_weight": 1.0, "normal_weight": 0.5})  # :186
+    # overlap_optimizer: AdamW + W^T refresh of a step run on a side stream under the next step's forward (full fine-tuning,
+    # fp32 moments, all-reduce mode; bit-identical); this loop only reads the parameters after the synchronize below
     engine = ForgetEngine(model, trainer, rc, total_steps=max_steps, warmup_steps=warmup, optimizer=rc.optimizer,
-                          dp_mode=rc.dp_mode)
+                          dp_mode=rc.dp_mode, overlap_optimizer=True)
 
     mine = shard_indices(len(data), rank, world)
     if not mine:

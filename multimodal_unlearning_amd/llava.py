@@ -337,6 +337,7 @@ class LlavaHIP(nn.Module):
         # (MMTrainerForgetting.compute_loss(..., _merge=g)): `.loss` is then the mean over the g equal row segments of each
         # segment's own mean CE — what the host loop would have averaged — instead of one mean over all tokens
         self.loss_segments = 1
+        self.param_events = None      # see _wait_params
         self.autograd_grads = False   # see enable_autograd_gradients
         self.ddp_compatible = False
         # torch DDP broadcasts module buffers from rank 0 at every forward; the frozen CLIP weights never change
@@ -670,9 +671,34 @@ class LlavaHIP(nn.Module):
                 off += r * c
         self.refresh_transposed_weights()
 
-    def refresh_transposed_weights(self):
+    def refresh_transposed_weights(self, prefix: Optional[str] = None):
+        """W^T copies from W; `prefix`: only the weights whose name starts with it (the pipelined optimiser refreshes a decoder
+        layer's copies right behind that layer's AdamW launch)."""
         for n, t in self.wT.items():
-            hip.transpose(self.w[n], t)
+            if prefix is None or n.startswith(prefix):
+                hip.transpose(self.w[n], t)
+
+    # ---- parameters updated asynchronously (ForgetEngine(overlap_optimizer=True)) ---------------------------------------------
+    # The engine may run AdamW and the W^T refresh of step k on a side stream, chunk by chunk in forward order, while the
+    # forward of step k + 1 already runs: `param_events` then maps a chunk ("pre" = everything in front of decoder layer 0,
+    # i = decoder layer i, "post" = final norm + lm_head) to the event recorded behind that chunk's update, and every forward
+    # waits for a chunk's event right before it first reads the chunk.
+    def _wait_params(self, key):
+        ev = self.param_events.get(key) if self.param_events else None
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+
+    def param_chunks(self):
+        """[(key, lo, hi)] in flat order: the ranges of `train_flat` a forward touches one after the other."""
+        L = self.cfg.text.num_layers
+        first = self.layer_grad_range(0)
+        last = self.layer_grad_range(L - 1)
+        out = [("pre", 0, first[0])] if first[0] > 0 else []
+        out += [(i, *self.layer_grad_range(i)) for i in range(L)]
+        n = self.train_flat.numel()
+        if last[1] < n:
+            out.append(("post", last[1], n))
+        return out
 
     def _use_t(self, M):
         return self.transposed_wgrad and not self.lora and M % 8 == 0 and M >= self.transposed_wgrad_min_m
@@ -1062,6 +1088,7 @@ class LlavaHIP(nn.Module):
         dt, I, H, D = t.hidden_size, t.intermediate_size, t.num_heads, t.head_dim
         scale = D ** -0.5
         p = f"text.layers.{i}."
+        self._wait_params(i)
         rstd1 = torch.empty(M, device=dev, dtype=torch.float32)
         hip.rmsnorm_fwd(h, w[p + "input_norm.weight"], y, rstd1, t.rms_norm_eps)
         qkv = torch.empty(M, 3 * dt, device=dev, dtype=BF)
@@ -1106,6 +1133,7 @@ class LlavaHIP(nn.Module):
         self._fwd_U = saved.setdefault("U", {}) if (save and self.lora) else None
         self._drop_seeds = (saved.setdefault("drop", {})
                             if (save and self.lora and self.lora_spec.dropout > 0 and self.training) else None)
+        self._wait_params("pre")
         img = None
         slot = None
         if pix is not None:
@@ -1132,6 +1160,7 @@ class LlavaHIP(nn.Module):
             if stop_layer is not None and i == stop_layer:
                 self._fwd_U = self._drop_seeds = None
                 return h.view(B, S, dt), saved
+        self._wait_params("post")
         if rows is not None:
             # loss-only forward: final norm + lm_head on the supervised rows only (padding slots are zero rows, their
             # targets are -100); returns the compact logits [len(rows), V]

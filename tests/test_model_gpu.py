@@ -562,6 +562,46 @@ def test_keep_act_t_is_equivalent(dev):
     assert torch.equal(res[0][1], res[1][1])
 
 
+@pytest.mark.parametrize("loss", ["grad_diff_forget_ce_retain_ce", "KL"])
+def test_overlapped_optimizer_is_bit_identical(dev, loss):
+    """ForgetEngine(overlap_optimizer=True): AdamW and the W^T refresh of a step run on a side stream, one chunk per decoder
+    layer in forward order, under the next step's forward, which waits for a chunk's event right before it reads the chunk.
+    Same kernels, same order per element: parameters, moments and W^T copies after four steps equal the serial engine's bit
+    for bit (merged and looped micro-batches; a no-grad forward between steps also honours the events)."""
+    from multimodal_unlearning_amd.engine import ForgetEngine
+    from multimodal_unlearning_amd.llava import LlavaHIP
+    from multimodal_unlearning_amd.trainer import MMTrainerForgetting
+
+    cfg = tiny_test_config(text_layers=3)
+    P = init_params(cfg, seed=0)
+    data = [[make_forget_batch(cfg, 2, 40, seed=90 + 10 * k + i, n_question=6) for i in range(2)] for k in range(4)]
+    res = {}
+    for overlap in (False, True):
+        for merge in (True, False):
+            model = LlavaHIP(cfg, P, device=dev)
+            teacher = LlavaHIP(cfg, teacher_params_from(P, seed=7), device=dev, trainable=False)
+            tr = MMTrainerForgetting(model=model, forget_loss=loss, teacher_model=teacher, loss_beta=1.0, l1_lambda=0, l0_lambda=0,
+                                     l_norm_from="zero")
+            eng = ForgetEngine(model, tr, ForgetConfig(lr=1e-3), total_steps=10, warmup_steps=1, merge_ga=merge,
+                               overlap_optimizer=overlap)
+            assert eng.overlap_optimizer == overlap
+            probes = []
+            for k, mbs in enumerate(data):
+                eng.step(mbs)
+                if k == 1:  # a forward that is not part of a step (evaluation between steps) sees the updated parameters
+                    with torch.no_grad():
+                        probes.append(float(model(**data[0][0]["forget"]).loss))
+            eng.finish_optimizer()
+            torch.cuda.synchronize()
+            res[overlap, merge] = (model.train_flat.detach().clone(), eng.m.clone(), eng.v.clone(),
+                                   model.wT["text.layers.2.down.weight"].clone(), model.wT["lm_head.weight"].clone(), probes)
+    for merge in (True, False):
+        a, b = res[True, merge], res[False, merge]
+        for x, y in zip(a[:5], b[:5]):
+            assert torch.equal(x, y), merge
+        assert a[5] == b[5]
+
+
 def test_dpo_variants_the_reference_computes_and_overwrites(models):
     """mm/trainer.py:390-396 assigns `loss` three times: DPO proper (-logsigmoid(0.1 * (pi - ref)).mean()), then -pi_logratios
     .mean(), then -idk_loss_current.mean() (what it trains on; golden-pinned elsewhere).  `loss_args={"dpo_variant": ...}`
