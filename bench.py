@@ -226,11 +226,11 @@ class KernelTimer:
                 setattr(hip, name, self._wrap_hbm(name, self.orig[name], cost))
         self.orig["attn_fwd"], self.orig["attn_bwd"] = hip.attn_fwd, hip.attn_bwd
 
-        def fwd(q, k, v, out, lse, kmask, B, S, H, D, scale, causal):
+        def fwd(q, k, v, out, lse, kmask, B, S, H, D, scale, causal, **kw):
             s = torch.cuda.current_stream()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(s)
-            r = self.orig["attn_fwd"](q, k, v, out, lse, kmask, B, S, H, D, scale, causal)
+            r = self.orig["attn_fwd"](q, k, v, out, lse, kmask, B, S, H, D, scale, causal, **kw)
             e1.record(s)
             fl = 4.0 * B * H * S * S * D * (0.5 if causal else 1.0)
             self.rec.setdefault(f"attn_fwd_kernel<{D},{'causal' if causal else 'full'}>", []).append(("flops", fl, e0, e1))

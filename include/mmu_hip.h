@@ -101,6 +101,11 @@ long long mmu_gemm_workspace_bytes(void);
  * kmask [B][S] int32 (1 = key may be attended; NULL = all). */
 int mmu_attn_fwd(const void* q, const void* k, const void* v, int ld, void* o, int ldo, float* lse,
                  const int* kmask, int B, int S, int H, int head_dim, float scale, int causal, void* stream);
+/* mmu_attn_fwd that also leaves O^T [H * head_dim][ldt] (ldt >= B * S, multiple of 8; head_dim 128, S % 8 == 0): the
+ * transposed activation of the o-projection's weight gradient (autograd's o_proj.weight.grad = dY^T O), written from the
+ * staging image of the row-major store — no transpose pass over O in the backward. */
+int mmu_attn_fwd_t(const void* q, const void* k, const void* v, int ld, void* o, int ldo, void* o_t, int ldt, float* lse,
+                   const int* kmask, int B, int S, int H, int head_dim, float scale, int causal, void* stream);
 /* head_dim 128 (Llama, causal) or 64 (CLIP tower, adapted by LoRA: non-causal); delta: fp32 workspace of 2 * B * H * S floats ([0]: rowsum(dO * O), [1]: lse * log2 e). */
 int mmu_attn_bwd(const void* q, const void* k, const void* v, int ld, const void* o, int ldo, const float* lse,
                  const int* kmask, const void* dout, int lddo, float* delta, void* dq, void* dk, void* dv,

@@ -280,8 +280,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
                 for (int r = 0; r < 16; ++r) o[dt][r] *= inv;
             u32x2 w[4][4];
             grad_words(o, hl, nullptr, nullptr, w);
+            // a.dT (forward, round 4): also leave O^T [H * D][ldt] — the A operand of the o-projection's weight gradient —
+            // read column-wise from the same staging image (mmu_attn_fwd_t; sequence lengths that are multiples of 8)
             store_tile32x128_via_lds<false>((MMU_LDS char*)smem + wave * 4096, w, lane, a.o + (rowbase + q0) * a.ldo + hh * D,
-                                            a.ldo, nullptr, 0, min(32, S - q0));
+                                            a.ldo, a.dT ? a.dT + (size_t)(hh * D) * a.ldt + rowbase + q0 : nullptr, a.ldt,
+                                            min(32, S - q0));
         }
         if (qvalid && hl == 0 && a.lse)
             a.lse[((size_t)b * a.H + hh) * S + qrow] = ltot > 0.f ? (m + __log2f(ltot)) * LN2 : INFINITY;
@@ -976,6 +979,24 @@ extern "C" int mmu_attn_fwd(const void* q, const void* k, const void* v, int ld,
     hipStream_t s = (hipStream_t)stream;
     if (head_dim == 128) return causal ? launch_fwd<128, true>(a, s) : launch_fwd<128, false>(a, s);
     return causal ? launch_fwd<64, true>(a, s) : launch_fwd<64, false>(a, s);
+}
+
+// mmu_attn_fwd that also leaves O^T = [H * head_dim][ldt] (ldt >= B * S, a multiple of 8): the transposed activation the
+// o-projection's weight gradient dW_o = dY^T O wants as its reduction-contiguous operand, written from the staging image the
+// row-major store goes through anyway (head_dim 128; B * S and S multiples of 8, else -1: the caller transposes O itself).
+extern "C" int mmu_attn_fwd_t(const void* q, const void* k, const void* v, int ld, void* o, int ldo, void* o_t, int ldt,
+                              float* lse, const int* kmask, int B, int S, int H, int head_dim, float scale, int causal,
+                              void* stream) {
+    AttnArgs a = {};
+    a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.ld = ld;
+    a.o = (bf16*)o; a.ldo = ldo; a.lse = lse; a.kmask = kmask;
+    a.B = B; a.S = S; a.H = H; a.scale = scale;
+    a.dT = (bf16*)o_t; a.ldt = ldt;
+    if (!attn_args_ok(a, head_dim) || head_dim != 128 || !o_t) return -1;
+    if ((S & 7) || (ldt & 7) || (long long)ldt < (long long)B * S || ((uintptr_t)o_t & 15) || ((uintptr_t)o & 15) || (ldo & 7))
+        return -1;
+    hipStream_t s = (hipStream_t)stream;
+    return causal ? launch_fwd<128, true>(a, s) : launch_fwd<128, false>(a, s);
 }
 
 // Backward (head_dim 128 or 64): needs q,k,v,o,lse of the forward plus dout; writes dq,dk,dv (row stride ldg,

@@ -38,6 +38,7 @@ SIGNATURES = {
     "mmu_gemm_set_tile_queue": [_vp, _ll],
     "mmu_gemm_reset_tile_queue": [],
     "mmu_attn_fwd": [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp],
+    "mmu_attn_fwd_t": [_vp, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp],
     "mmu_attn_bwd": [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i,
                      _vp],
     "mmu_attn_bwd_rope": [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i,
@@ -307,10 +308,17 @@ def gemm_set_tile(tile: int):
 
 
 # ------------------------------------------------------------------------------------------- attention
-def attn_fwd(q, k, v, out, lse, kmask, B, S, H, head_dim, scale, causal):
-    """q/k/v: 2-D views [B*S, H*head_dim] (row stride = ld, e.g. slices of a fused qkv buffer)."""
+def attn_fwd(q, k, v, out, lse, kmask, B, S, H, head_dim, scale, causal, out_t=None):
+    """q/k/v: 2-D views [B*S, H*head_dim] (row stride = ld, e.g. slices of a fused qkv buffer).  out_t (bf16 [H*head_dim,
+    B*S], optional; head_dim 128, S % 8 == 0): also leave out^T, the o-projection's weight-gradient operand."""
     _bf16c(q, k, v, out)
     assert q.stride(0) == k.stride(0) == v.stride(0) and q.stride(1) == 1
+    if out_t is not None:
+        _bf16c(out_t)
+        assert out_t.shape == (H * head_dim, B * S) and out_t.stride(1) == 1
+        _check(load().mmu_attn_fwd_t(_p(q), _p(k), _p(v), q.stride(0), _p(out), out.stride(0), _p(out_t), out_t.stride(0),
+                                     _p(lse), _p(kmask), B, S, H, head_dim, float(scale), int(causal), _stream()), "mmu_attn_fwd_t")
+        return out
     rc = load().mmu_attn_fwd(_p(q), _p(k), _p(v), q.stride(0), _p(out), out.stride(0), _p(lse), _p(kmask), B, S, H,
                              head_dim, float(scale), int(causal), _stream())
     _check(rc, "mmu_attn_fwd")

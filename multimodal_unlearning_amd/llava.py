@@ -293,6 +293,7 @@ class LlavaHIP(nn.Module):
         self.fuse_rope = os.environ.get("MMU_NO_ROPE_FUSION", "0") != "1"  # A/B switch
         self.fuse_dqkv_t = os.environ.get("MMU_NO_DQKV_T", "0") != "1"     # A/B switch: dqkv^T written by attention backward
         self.fuse_swiglu = os.environ.get("MMU_NO_SWIGLU_FUSION", "0") != "1"  # A/B switch: SwiGLU fwd / bwd in the GEMM epilogues
+        self.attn_out_t = os.environ.get("MMU_NO_ATTN_OT", "0") != "1"        # A/B switch: a^T written by the attention forward
         # activation recompute = the reference's `model.gradient_checkpointing_enable()` (mm/forget.py:123-124): the forward
         # keeps one [tokens, d] tensor per decoder layer instead of ~92-114 KB per token and layer, the backward pays one more
         # forward of every layer (+33 % FLOPs).  Buys micro-batch where HBM is the limit (13B + teacher + fp32 moments).
@@ -785,7 +786,7 @@ class LlavaHIP(nn.Module):
         gradient and row statistics.  The step loop sizes merged micro-batches with it (ForgetEngine._groups)."""
         t = self.cfg.text
         d, I, V, L = t.hidden_size, t.intermediate_size, t.vocab_size, t.num_layers
-        per_layer = 12 * d + 4 * I + (2 * I if self.keep_act_t else 0)
+        per_layer = 12 * d + 4 * I + (2 * I + 2 * d if self.keep_act_t else 0)   # keep_act_t: act^T and a^T
         if self.lora:
             per_layer += 2 * I + 2 * d  # act and the x A^T products kept for the adapter wgrads
         work = 12 * I + 24 * d
@@ -1095,7 +1096,11 @@ class LlavaHIP(nn.Module):
         self._qkv_fwd(p + "qkv.weight", y, qkv, pos, H, D, dt)
         a = torch.empty(M, dt, device=dev, dtype=BF)
         lse = torch.empty(B, H, S, device=dev, dtype=torch.float32) if save else None
-        hip.attn_fwd(qkv[:, :dt], qkv[:, dt:2 * dt], qkv[:, 2 * dt:], a, lse, kmask, B, S, H, D, scale, True)
+        # with keep_act_t the attention forward also leaves a^T (the o-projection's wgrad operand, + M*d*2 B per layer: 8.5 GB
+        # at 7B / 30 sequences) from the staging image of its row-major store: the backward then transposes dh2 only
+        aT = (torch.empty(dt, M, device=dev, dtype=BF)
+              if (save and self.keep_act_t and self.attn_out_t and self._use_t(M) and D == 128 and S % 8 == 0) else None)
+        hip.attn_fwd(qkv[:, :dt], qkv[:, dt:2 * dt], qkv[:, 2 * dt:], a, lse, kmask, B, S, H, D, scale, True, out_t=aT)
         h2 = torch.empty(M, dt, device=dev, dtype=BF)
         self._lin_fwd(p + "o.weight", a, h2, resid=h)
         rstd2 = torch.empty(M, device=dev, dtype=torch.float32)
@@ -1118,7 +1123,7 @@ class LlavaHIP(nn.Module):
         self._lin_fwd(p + "down.weight", act, hn, resid=h2)
         if save and actT is None and self.keep_act_t and self.lora:
             actT = act  # LoRA sweep: the row-major act is the down-proj adapter's wgrad operand (no transposed path)
-        return hn, (rstd1, qkv, a, lse, h2, rstd2, gu, actT)
+        return hn, (rstd1, qkv, (a, aT) if aT is not None else a, lse, h2, rstd2, gu, actT)
 
     def _forward_impl(self, ids, kmask, pix, pos, save: bool, stop_layer: Optional[int] = None,
                       rows: Optional[torch.Tensor] = None):
@@ -1308,7 +1313,15 @@ class LlavaHIP(nn.Module):
                             True)
             # attention
             da = dh  # reuse the buffer of the (now consumed) upstream gradient
-            self._lin_bwd(p + "o.weight", dh2, a, da)
+            aT = None
+            if isinstance(a, tuple):
+                a, aT = a
+            if aT is not None and use_t:   # a^T came out of the attention forward: only dh2 is transposed here
+                self._wgrad_t(dh2, None, aT, p + "o.weight")
+                self._dgrad(dh2, p + "o.weight", da)
+                del aT
+            else:
+                self._lin_bwd(p + "o.weight", dh2, a, da)
             dqkv = torch.empty(M, 3 * dt, device=dev, dtype=BF)
             # the backward kernels also leave dqkv^T for the q|k|v weight gradient (the persistent dK/dV kernel writes its
             # two thirds from the staging image it already has; only valid while RoPE is fused into the same stores)

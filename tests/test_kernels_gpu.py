@@ -1220,3 +1220,23 @@ def test_dropout_kernel_mask_is_a_function_of_seed_and_index(dev):
     assert torch.equal(z, ref)
     hip.dropout(y, ref, 0.0, 5)
     assert torch.equal(ref, y)
+
+
+@pytest.mark.parametrize("B,H,S,causal", [(2, 3, 136, True), (1, 2, 1088, True), (3, 1, 64, False)])
+def test_attn_fwd_transposed_output(dev, B, H, S, causal):
+    """mmu_attn_fwd_t: O^T [H * 128, B * S] written from the staging image of the row-major store == O.t(), bit for bit, and
+    O / lse equal to the plain forward's (S multiples of 8 incl. a ragged last 32-row block)."""
+    D = 128
+    qkv = _randn((B * S, 3 * H * D), dev, 0.5, seed=7)
+    q, k, v = qkv[:, :H * D], qkv[:, H * D:2 * H * D], qkv[:, 2 * H * D:]
+    o0, o1 = torch.empty(B * S, H * D, device=dev, dtype=BF), torch.full((B * S, H * D), 7.0, device=dev, dtype=BF)
+    oT = torch.full((H * D, B * S), 7.0, device=dev, dtype=BF)
+    l0, l1 = torch.empty(B, H, S, device=dev), torch.empty(B, H, S, device=dev)
+    hip.attn_fwd(q, k, v, o0, l0, None, B, S, H, D, D ** -0.5, causal)
+    hip.attn_fwd(q, k, v, o1, l1, None, B, S, H, D, D ** -0.5, causal, out_t=oT)
+    torch.cuda.synchronize()
+    assert torch.equal(o0, o1) and torch.equal(l0, l1)
+    assert torch.equal(oT, o0.t().contiguous())
+    with pytest.raises(hip.HipKernelError):   # S not a multiple of 8: the transposed copy moves groups of 8 tokens
+        hip.attn_fwd(q[: 2 * 36], k[: 2 * 36], v[: 2 * 36], o1[: 2 * 36], None, None, 2, 36 - 1, H, D, D ** -0.5, causal,
+                     out_t=torch.empty(H * D, 2 * 35 + 2, device=dev, dtype=BF)[:, : 2 * 35])
